@@ -1,0 +1,33 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+WEIGHTS = ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_fit_cases():
+    return sorted(os.path.basename(p)[4:-4] for p in glob.glob(os.path.join(GOLDEN, "fit_*.npz")))
+
+
+def load_golden(kind, name):
+    z = np.load(os.path.join(GOLDEN, "%s_%s.npz" % (kind, name)), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """the CPU restatement (test infrastructure)"""
+    from oracle import oracle as orc
+    orc.build()
+    return orc
