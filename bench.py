@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""bench.py -- (user, item, neg) pairwise updates/s of the RankFM SGD hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE EPOCH of the hot path (BPR SGD, k=64) over the rank's resident interaction shard: the SGD
+wavefront kernel over all rows + the epoch tail (finiteness check) + -- for N > 1 -- the RCCL all-reduce of the
+item-side deltas.  Workload = BASELINE.json config 2 (synthetic 100k users x 50k items x 5M interactions,
+factors=64, loss='bpr') per GPU; for N > 1 every rank owns its own 100k-user / 5M-interaction shard over the
+shared 50k items (weak scaling; the 8-GPU total is config-4-shaped: 800k users, 40M interactions).  Inputs are
+resident in HBM when the timed region starts.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus:
+  roofline     achieved = algorithmic bytes (24F+32 = 1568 B per update) x rows per launch / average
+               HIP-event duration of the SGD kernel launch, against the 8 TB/s HBM3E peak
+  cpu_baseline the CPU restatement of the reference's `_fit` (oracle/, "port"; MT19937 + linear membership scan like
+               the reference) timed on ONE host core (the reference is single-threaded) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
+
+
+def algorithmic_bytes_per_update(F, n_uf=0, n_if=0, draws=1.0):
+    """reads (u,i) 8 + sw 4 + perm 4 + v_u 4F + v_i[i] 4F + w_i 4 + per draw (v_i[j] 4F + w_i[j] 4);
+    writes v_u, v_i[i], v_i[j] 3*4F + 8  ->  BPR 24F + 32; each extra WARP draw adds 4F + 4; dense features add
+    4P + 4Q(1 + draws)"""
+    b = 24 * F + 32 + (draws - 1.0) * (4 * F + 4)
+    if n_uf or n_if:
+        b += 4 * n_uf + 4 * n_if * (1 + draws)
+    return b
+
+
+def cpu_baseline(pairs, csr, F, seconds_budget=25.0):
+    """time the CPU restatement (oracle = checker infrastructure, used here only as the reported baseline)"""
+    from oracle import oracle as orc
+    from rankfm_amd import synthetic
+    U, I, N = len(csr.offsets) - 1, int(pairs[:, 1].max()) + 1, len(pairs)
+    I = max(I, 2)
+    w = synthetic.init_weights(U, I, F, seed=1492)
+    x_uf, x_if = np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32)
+    sw = np.ones(N, dtype=np.float32)
+    rng = np.random.default_rng(0)
+
+    def run(n_rows):
+        perm = rng.permutation(N)[:n_rows].astype(np.int32)
+        sub = np.ascontiguousarray(pairs[perm])                   # a random sample of the same workload's rows
+        p = np.arange(n_rows, dtype=np.int32)[None, :]
+        ww = {k: v.copy() for k, v in w.items()}
+        t0 = time.perf_counter()
+        orc.fit(sub, sw[:n_rows], csr.offsets, csr.items, x_uf, x_if, ww["w_i"], ww["w_if"], ww["v_u"], ww["v_i"],
+                ww["v_uf"], ww["v_if"], 0.01, 0.1, 0.1, "constant", 0.25, 1, 1, perms=p,
+                rng_mode=orc.RNG_MT19937, seed=1492, membership="linear")
+        return time.perf_counter() - t0
+
+    probe = min(N, 500_000)
+    t = run(probe)
+    rate = probe / t
+    n_rows = int(min(N, max(probe, rate * seconds_budget * 0.6)))
+    t = run(n_rows)
+    return dict(value=n_rows / t, unit="updates/s", cores=1, kind="port",
+                sample="%d randomly sampled rows of the same workload, 1 epoch, oracle/rfm_oracle.c (gcc -O2 -ffast-math, "
+                       "MT19937 + linear membership scan like the reference), %.1f s on 1 core of %d" % (n_rows, t, os.cpu_count() or 0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workgroups", type=int, default=0)
+    ap.add_argument("--rows-per-launch", type=int, default=0)
+    ap.add_argument("--zipf", type=float, default=1.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from rankfm_amd import synthetic
+    from rankfm_amd.distributed import SHARED_NAMES, broadcast_from_rank0, make_device_trainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: rankfm_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = synthetic.CONFIGS[args.config]
+    U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
+    n_uf, n_if = cfg.get("n_user_features", 0), cfg.get("n_item_features", 0)
+    # each rank generates ITS OWN user shard (different seed) over the shared item catalogue
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=1000 * rank, zipf_s=args.zipf)
+    w = synthetic.init_weights(U, I, F, n_uf, n_if, seed=1492 + rank)
+    x_uf = synthetic.make_features(U, n_uf, 7 + rank) if n_uf else np.zeros((U, 1), np.float32)
+    x_if = synthetic.make_features(I, n_if, 8) if n_if else np.zeros((I, 1), np.float32)
+    shard = dict(interactions=pairs, sample_weight=np.ones(N, np.float32), csr_offsets=csr.offsets, csr_items=csr.items,
+                 x_uf=x_uf, v_u=w["v_u"])
+    hyper = dict(alpha=0.01, beta=0.1, learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25,
+                 max_samples=cfg["max_samples"])
+    trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
+                                        seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
+                                        has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0))
+    broadcast_from_rank0([trainer.shared.flat])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    epoch = 0
+    for _ in range(args.warmup):
+        trainer.run_epoch(epoch)
+        epoch += 1
+    kernel_ms, draws = [], 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rep = trainer.run_epoch(epoch)
+        kernel_ms.append(float(rep["sgd_kernel_ms"][0]))
+        draws += int(rep["n_draws"][0])
+        epoch += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ll_last = float(rep["log_likelihood"][0])
+    assert np.isfinite(ll_last), "training diverged"
+
+    if rank == 0:
+        total_updates = float(N) * world * args.steps
+        value = total_updates / elapsed
+        launches = rep["launches_per_epoch"]
+        mean_draws = draws / (float(N) * args.steps)
+        bytes_per_update = algorithmic_bytes_per_update(F, n_uf, n_if, mean_draws)
+        k_ms = float(np.mean(kernel_ms)) / launches                 # average duration of ONE SGD launch
+        rows_per_launch = N / launches
+        achieved = bytes_per_update * rows_per_launch / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, when collected
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s_hbm_bytes_per_launch" % args.config)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "(user,item,neg) pairwise updates/sec at k=64; achieved HBM GB/s vs peak",
+            "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: synthetic %d users x %d items x %d interactions per GPU, factors=%d, loss=%s, "
+                                   "zipf_s=%g, hogwild fp32 atomics, counter RNG" % (args.config, U, I, N, F, cfg["loss"], args.zipf),
+                       "n_users_total": U * world, "n_interactions_total": N * world, "parallelism": "user-shard dp%d" % world,
+                       "sgd_launches_per_epoch": launches, "waves_per_launch": rep["waves_per_launch"],
+                       "mean_draws_per_update": mean_draws, "final_mean_ll_per_update": ll_last / N},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "rfm::sgd_kernel", "kernel_ms_per_launch": k_ms,
+                         "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pairs, csr, F)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

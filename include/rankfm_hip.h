@@ -1,0 +1,170 @@
+/* rankfm_hip.h -- C ABI of the MI355X-native RankFM training engine (librankfm_hip.so).
+ *
+ * Drop-in boundary for the reference's private operator functions (all paths relative to the
+ * etlundquist/rankfm tree):
+ *
+ *   rfm_fit_host / rfm_fit_device      replace  `_fit`        rankfm/_rankfm.pyx:122-342
+ *                                      called from            rankfm/rankfm.py:304-324
+ *   rfm_predict_host / _device         replace  `_predict`    rankfm/_rankfm.pyx:345-390
+ *                                      called from            rankfm/rankfm.py:347-357
+ *   rfm_recommend_host / _device       replace  `_recommend`  rankfm/_rankfm.pyx:393-460
+ *                                      called from            rankfm/rankfm.py:381-394
+ *
+ * Conventions kept from the reference boundary: interactions int32 [N,2] C-contiguous; every
+ * weight / feature / sample-weight array float32 C-contiguous; the six weight arrays
+ * w_i[I], w_if[Q], v_u[U,F], v_i[I,F], v_uf[P,F], v_if[Q,F] are updated IN PLACE and nothing is
+ * returned; absent features are the [U,1] / [I,1] all-zero placeholders with [1,F] / [1] zero
+ * tables (rankfm/rankfm.py:199,211,224,236,244) and `has_*_features` carries the reference's
+ * `x.any()` test (rankfm/_rankfm.pyx:193-194).
+ *
+ * Differences, all forced by the C boundary or by running on a GPU:
+ *   - the per-user item dict (rankfm/rankfm.py:174) is passed as CSR: offsets int64 [U+1] and the
+ *     users' sorted item indexes int32 [nnz] back to back;
+ *   - exceptions become status codes (see rfm_status); the caller turns RFM_ERR_NONFINITE + k into
+ *     the reference's AssertionError for array k (order of rankfm/_rankfm.pyx:98-103) and
+ *     RFM_ERR_UNKNOWN_SCHEDULE into its ValueError (rankfm/_rankfm.pyx:225);
+ *   - the epoch shuffle (np.random.shuffle, rankfm/_rankfm.pyx:227) is either passed in explicitly
+ *     (`perms`, int32 [epochs,N]) or generated on the device by a keyed bijection (include/rfm_rng.h);
+ *   - nothing is printed: per-epoch log-likelihood and L2 penalty come back in rfm_fit_report and
+ *     the caller prints them when verbose (rankfm/_rankfm.pyx:332-336).
+ *
+ * No torch / numpy types appear here: plain pointers, sizes and a HIP stream handle as void*.
+ */
+#ifndef RANKFM_HIP_H
+#define RANKFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFM_ABI_VERSION 1
+
+typedef enum rfm_status {
+    RFM_OK = 0,
+    RFM_ERR_BAD_ARG = -1,           /* null pointer, negative size, max_samples < 1, ... */
+    RFM_ERR_UNKNOWN_SCHEDULE = -2,  /* reference: ValueError('unknown [learning_schedule]') */
+    RFM_ERR_NO_DEVICE = -3,         /* no HIP device / wrong architecture: the engine never falls back to a CPU */
+    RFM_ERR_HIP = -4,               /* a HIP runtime call failed; rfm_last_error() has the text */
+    RFM_ERR_UNSUPPORTED = -5,       /* shape outside the compiled kernel set (see rfm_fit_supported) */
+    RFM_ERR_USER_SATURATED = -6,    /* a user has interacted with every item: rejection sampling cannot end */
+    RFM_ERR_WORKSPACE = -7,         /* workspace missing or smaller than rfm_fit_workspace_bytes() */
+    RFM_ERR_NONFINITE = 100         /* + k, k = 0..5 -> w_i, w_if, v_u, v_i, v_uf, v_if (assert_finite order) */
+} rfm_status;
+
+/* learning_schedule (rankfm/_rankfm.pyx:220-225) */
+#define RFM_SCHEDULE_CONSTANT 0
+#define RFM_SCHEDULE_INVSCALING 1
+
+/* execution mode */
+#define RFM_MODE_HOGWILD 0  /* production: thousands of wavefronts, fp32 atomic updates, counter RNG only */
+#define RFM_MODE_SERIAL 1   /* one wavefront walks the shuffled rows in order with plain read-modify-write:
+                               the reference's sequential semantics (parity / debugging mode) */
+
+/* negative-draw stream */
+#define RFM_RNG_MT19937 0   /* reference stream: MT19937, `% I` (serial mode only; needs explicit perms) */
+#define RFM_RNG_COUNTER 1   /* counter-based draws keyed by (seed, epoch, row, attempt): include/rfm_rng.h */
+
+typedef struct rfm_fit_config {
+    int64_t n_interactions;        /* N */
+    int32_t n_users;               /* U */
+    int32_t n_items;               /* I */
+    int32_t n_user_features;       /* P  (1 when absent) */
+    int32_t n_item_features;       /* Q  (1 when absent) */
+    int32_t n_factors;             /* F */
+    int32_t has_user_features;     /* reference: int(x_uf.any()) */
+    int32_t has_item_features;     /* reference: int(x_if.any()) */
+    float alpha;                   /* L2 on w_i, v_u, v_i */
+    float beta;                    /* L2 on w_if, v_uf, v_if */
+    float learning_rate;
+    int32_t learning_schedule;     /* RFM_SCHEDULE_* */
+    float learning_exponent;
+    int32_t max_samples;           /* 1 = BPR (rankfm/rankfm.py:294-295), >1 = WARP */
+    int32_t epochs;                /* epochs to run in this call */
+    int32_t epoch_begin;           /* absolute index of the first one (learning-rate decay, counter keys) */
+    int32_t mode;                  /* RFM_MODE_* */
+    int32_t rng;                   /* RFM_RNG_* */
+    uint32_t seed;                 /* MT seed (reference: 1492) or counter seed */
+    int32_t check_finite;          /* 1: epoch-end finiteness check (reference behaviour), 0: skip */
+    int32_t want_penalty;          /* 1: also return the L2 penalty per epoch (verbose printing) */
+    int32_t n_workgroups;          /* 0 = auto (hogwild); ignored in serial mode */
+    int32_t rows_per_launch;       /* 0 = one launch per epoch; >0 splits an epoch into several launches */
+    int32_t reserved[4];
+} rfm_fit_config;
+
+/* All pointers of one struct live in the same memory space: device memory for the *_device entry
+ * points, host memory for the *_host ones. */
+typedef struct rfm_fit_buffers {
+    const int32_t *interactions;   /* [N,2] (user index, item index) */
+    const float *sample_weight;    /* [N] */
+    const int64_t *csr_offsets;    /* [U+1] */
+    const int32_t *csr_items;      /* [csr_offsets[U]] sorted within each user */
+    const float *x_uf;             /* [U,P] */
+    const float *x_if;             /* [I,Q] */
+    float *w_i;                    /* [I]    in/out */
+    float *w_if;                   /* [Q]    in/out */
+    float *v_u;                    /* [U,F]  in/out */
+    float *v_i;                    /* [I,F]  in/out */
+    float *v_uf;                   /* [P,F]  in/out */
+    float *v_if;                   /* [Q,F]  in/out */
+    const int32_t *perms;          /* [epochs,N] visiting order per epoch, or NULL = device-generated */
+    void *workspace;               /* device scratch of >= rfm_fit_workspace_bytes() (device entry only) */
+    size_t workspace_bytes;
+} rfm_fit_buffers;
+
+/* Host-side results; every pointer may be NULL. */
+typedef struct rfm_fit_report {
+    double *log_likelihood;        /* [epochs] sum over updates of log(sigmoid(pairwise utility)) */
+    double *reg_penalty;           /* [epochs] alpha*(|w_i|^2+|v_u|^2+|v_i|^2) + beta*(|w_if|^2+|v_uf|^2+|v_if|^2) */
+    float *sgd_kernel_ms;          /* [epochs] HIP-event time of the epoch's SGD launch(es) */
+    int64_t *n_draws;              /* [epochs] accepted negative draws (== N for BPR) */
+    int32_t epochs_done;           /* epochs completed before an error, or `epochs` */
+    int32_t nonfinite_array;       /* -1, or 0..5 when the status is RFM_ERR_NONFINITE + k */
+    int32_t launches_per_epoch;
+    int32_t waves_per_launch;
+} rfm_fit_report;
+
+int rfm_abi_version(void);
+const char *rfm_status_string(int status);
+const char *rfm_last_error(void);            /* text of the last RFM_ERR_HIP on this thread */
+int rfm_device_count(void);                  /* number of gfx950 devices visible, 0 if none */
+int rfm_fit_supported(const rfm_fit_config *cfg);          /* RFM_OK or the error rfm_fit_* would return */
+size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg); /* 0 on a bad config */
+
+/* `_fit` on buffers already resident in HBM.  Work is enqueued on `hip_stream` (a hipStream_t; NULL =
+ * the default stream); the call returns after one stream synchronisation at the end, when the report
+ * is filled.  Weights are updated in place in device memory. */
+int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *dev, void *hip_stream, rfm_fit_report *report);
+
+/* `_fit` on host (numpy) buffers: uploads to `device`, runs rfm_fit_device, downloads the six weight
+ * arrays back into the caller's memory.  This is the 1:1 replacement of the reference call site. */
+int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *host, int device, rfm_fit_report *report);
+
+/* ---- `_predict` (rankfm/_rankfm.pyx:345-390): pairs are float32 [n,2] indexes, NaN = unknown id ---- */
+typedef struct rfm_model_view {
+    int32_t n_users, n_items, n_user_features, n_item_features, n_factors;
+    int32_t has_user_features, has_item_features;
+    const float *x_uf, *x_if, *w_i, *w_if, *v_u, *v_i, *v_uf, *v_if;
+} rfm_model_view;
+
+int rfm_predict_device(const rfm_model_view *dev_model, int64_t n_pairs, const float *dev_pairs, float *dev_scores,
+                       void *hip_stream);
+int rfm_predict_host(const rfm_model_view *host_model, int64_t n_pairs, const float *pairs, float *scores, int device);
+
+/* ---- `_recommend` (rankfm/_rankfm.pyx:393-460): users float32 [n] indexes (NaN = unknown), output float32
+ * [n, n_rec] item indexes ranked by descending utility, optionally skipping the user's CSR items ---- */
+int rfm_recommend_device(const rfm_model_view *dev_model, int64_t n_rec_users, const float *dev_users,
+                         const int64_t *dev_csr_offsets, const int32_t *dev_csr_items, int32_t n_rec,
+                         int32_t filter_previous, float *dev_rec_items, void *workspace, size_t workspace_bytes,
+                         void *hip_stream);
+size_t rfm_recommend_workspace_bytes(const rfm_model_view *model, int64_t n_rec_users, int32_t n_rec);
+int rfm_recommend_host(const rfm_model_view *host_model, int64_t n_rec_users, const float *users,
+                       const int64_t *csr_offsets, const int32_t *csr_items, int32_t n_rec, int32_t filter_previous,
+                       float *rec_items, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANKFM_HIP_H */

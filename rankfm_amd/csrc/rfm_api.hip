@@ -1,0 +1,439 @@
+// rfm_api.hip -- C ABI of librankfm_hip.so: host-side orchestration of `_fit` on one MI355X.
+//
+// Replaces the epoch wrapper of the reference's `_fit` (rankfm/_rankfm.pyx:182-228, 329-342): MT seeding,
+// shape inference, learning-rate schedule, the epoch loop, the epoch-end finiteness assertion
+// (assert_finite, :95-103) and the verbose penalty (reg_penalty, :106-116).  The row loop itself is the
+// wavefront kernel in rfm_sgd.hpp.  See include/rankfm_hip.h for the boundary contract.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rankfm_hip.h"
+#include "rfm_sgd.hpp"
+
+namespace rfm {
+#define RFM_DECLARE_SHAPE(name) const sgd_launch_fn *sgd_table_##name();
+RFM_DECLARE_SHAPE(v4_g4_k1) RFM_DECLARE_SHAPE(v4_g8_k1) RFM_DECLARE_SHAPE(v4_g16_k1) RFM_DECLARE_SHAPE(v4_g32_k1)
+RFM_DECLARE_SHAPE(v4_g64_k1) RFM_DECLARE_SHAPE(v4_g64_k2)
+RFM_DECLARE_SHAPE(v1_g4_k1) RFM_DECLARE_SHAPE(v1_g16_k1) RFM_DECLARE_SHAPE(v1_g64_k1) RFM_DECLARE_SHAPE(v1_g64_k2)
+RFM_DECLARE_SHAPE(v1_g64_k4)
+
+struct ShapeEntry { int vec, group, kpl, max_f; const sgd_launch_fn *(*table)(); };
+static const ShapeEntry kShapes[] = {
+    {4, 4, 1, 16, sgd_table_v4_g4_k1},   {4, 8, 1, 32, sgd_table_v4_g8_k1},    {4, 16, 1, 64, sgd_table_v4_g16_k1},
+    {4, 32, 1, 128, sgd_table_v4_g32_k1}, {4, 64, 1, 256, sgd_table_v4_g64_k1}, {4, 64, 2, 512, sgd_table_v4_g64_k2},
+    {1, 4, 1, 4, sgd_table_v1_g4_k1},     {1, 16, 1, 16, sgd_table_v1_g16_k1},  {1, 64, 1, 64, sgd_table_v1_g64_k1},
+    {1, 64, 2, 128, sgd_table_v1_g64_k2}, {1, 64, 4, 256, sgd_table_v1_g64_k4},
+};
+
+// smallest row-group shape that holds F factors: 16-byte chunks when F is a multiple of 4
+static const ShapeEntry *pick_shape(int F) {
+    const int vec = (F % 4 == 0) ? 4 : 1;
+    for (const ShapeEntry &s : kShapes)
+        if (s.vec == vec && F <= s.max_f) return &s;
+    return nullptr;
+}
+
+static thread_local std::string g_last_error;
+
+static int hip_fail(hipError_t e, const char *what) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    g_last_error = buf;
+    return RFM_ERR_HIP;
+}
+#define RFM_HIP(call)                                            \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);        \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// epoch tail: finiteness of the six weight arrays (assert_finite) and, optionally, their squared norms
+// ---------------------------------------------------------------------------------------------
+struct TailArgs {
+    const float *ptr[6];
+    unsigned long long len[6];
+    double *sumsq;            // [6] or nullptr
+    unsigned int *nonfinite;  // bit k set when array k holds a non-finite value
+};
+
+template <bool PENALTY>
+__global__ void __launch_bounds__(256) tail_kernel(const TailArgs t) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned bad = 0;
+    for (int k = 0; k < 6; ++k) {
+        const float *p = t.ptr[k];
+        const unsigned long long n = t.len[k];
+        const unsigned long long n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (n >> 2) : 0;
+        float acc = 0.0f;
+        unsigned b = 0;
+        const float4 *p4 = reinterpret_cast<const float4 *>(p);
+        for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4;
+             idx += (unsigned long long)gridDim.x * blockDim.x) {
+            const float4 v = p4[idx];
+            const float s = v.x + v.y + v.z + v.w;
+            // a sum of four finite floats can only be non-finite by overflow near 3.4e38, which assert_finite's
+            // np.sum would flag as well
+            b |= ((__float_as_uint(s) & 0x7f800000u) == 0x7f800000u);
+            if (PENALTY) acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (unsigned long long idx = (n4 << 2) + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+             idx += (unsigned long long)gridDim.x * blockDim.x) {
+            const float v = p[idx];
+            b |= ((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u);
+            if (PENALTY) acc += v * v;
+        }
+        if (b) bad |= (1u << k);
+        if (PENALTY) {
+            double d = (double)acc;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) d += __shfl_xor(d, m);
+            if (lane == 0) red[wid] = d;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const double tot = red[0] + red[1] + red[2] + red[3];
+                if (tot != 0.0) unsafeAtomicAdd(t.sumsq + k, tot);
+            }
+            __syncthreads();
+        }
+    }
+    if (bad) atomicOr(t.nonfinite, bad);
+}
+
+// a user whose list holds every item would make the rejection sampler spin forever (rankfm/_rankfm.pyx:250-253)
+__global__ void degree_check_kernel(const int64_t *__restrict__ off, int n_users, int n_items, unsigned int *flag) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n_users && off[u + 1] - off[u] >= (int64_t)n_items) atomicOr(flag, 2u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout (device)
+// ---------------------------------------------------------------------------------------------
+struct Workspace {
+    double *ll;                   // [epochs]
+    unsigned long long *draws;    // [epochs]
+    double *sumsq;                // [epochs][6]
+    unsigned int *nonfinite;      // [epochs]
+    unsigned int *error_flags;    // [1] (+pad)
+    uint32_t *mt_state;           // [625] (+pad)
+    float *multiplier;            // [max_samples + 1]
+    size_t bytes;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static Workspace carve(void *base, int epochs, int max_samples) {
+    Workspace w;
+    char *p = (char *)base;
+    size_t o = 0;
+    w.ll = (double *)(p + o);                    o += align_up(sizeof(double) * epochs);
+    w.draws = (unsigned long long *)(p + o);     o += align_up(sizeof(unsigned long long) * epochs);
+    w.sumsq = (double *)(p + o);                 o += align_up(sizeof(double) * 6 * epochs);
+    w.nonfinite = (unsigned int *)(p + o);       o += align_up(sizeof(unsigned int) * epochs);
+    w.error_flags = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int) * 4);
+    w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
+    w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
+    w.bytes = o;
+    return w;
+}
+
+static int validate(const rfm_fit_config *c) {
+    if (!c) return RFM_ERR_BAD_ARG;
+    if (c->n_interactions < 0 || c->n_interactions > 0x7fffffffLL) return RFM_ERR_BAD_ARG;   // int32 row ids, like the reference
+    if (c->n_users < 1 || c->n_items < 2 || c->n_user_features < 1 || c->n_item_features < 1 || c->n_factors < 1)
+        return RFM_ERR_BAD_ARG;
+    if (c->max_samples < 1 || c->epochs < 1 || c->epoch_begin < 0) return RFM_ERR_BAD_ARG;
+    if (c->learning_schedule != RFM_SCHEDULE_CONSTANT && c->learning_schedule != RFM_SCHEDULE_INVSCALING)
+        return RFM_ERR_UNKNOWN_SCHEDULE;
+    if (c->mode != RFM_MODE_HOGWILD && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;
+    if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
+    if (c->rng == RFM_RNG_MT19937 && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;   // one serial stream
+    if (!pick_shape(c->n_factors)) return RFM_ERR_UNSUPPORTED;
+    return RFM_OK;
+}
+
+static int g_sm_count = 0;
+
+static int device_ok() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RFM_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return RFM_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_last_error = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only";
+        return RFM_ERR_NO_DEVICE;
+    }
+    g_sm_count = prop.multiProcessorCount;
+    return RFM_OK;
+}
+
+}  // namespace rfm
+
+using namespace rfm;
+
+extern "C" {
+
+int rfm_abi_version(void) { return RFM_ABI_VERSION; }
+
+const char *rfm_last_error(void) { return g_last_error.c_str(); }
+
+const char *rfm_status_string(int s) {
+    switch (s) {
+        case RFM_OK: return "ok";
+        case RFM_ERR_BAD_ARG: return "bad argument";
+        case RFM_ERR_UNKNOWN_SCHEDULE: return "unknown [learning_schedule]";
+        case RFM_ERR_NO_DEVICE: return "no MI355X (gfx950) device available - the engine has no CPU fallback";
+        case RFM_ERR_HIP: return "HIP runtime error";
+        case RFM_ERR_UNSUPPORTED: return "unsupported shape";
+        case RFM_ERR_USER_SATURATED: return "a user has interacted with every item - negative sampling cannot terminate";
+        case RFM_ERR_WORKSPACE: return "workspace missing or too small";
+        case RFM_ERR_NONFINITE + 0: return "item weights [w_i] are not finite - try decreasing feature/sample_weight magnitudes";
+        case RFM_ERR_NONFINITE + 1: return "item feature weights [w_if] are not finite - try decreasing feature/sample_weight magnitudes";
+        case RFM_ERR_NONFINITE + 2: return "user factors [v_u] are not finite - try decreasing feature/sample_weight magnitudes";
+        case RFM_ERR_NONFINITE + 3: return "item factors [v_i] are not finite - try decreasing feature/sample_weight magnitudes";
+        case RFM_ERR_NONFINITE + 4: return "user-feature factors [v_uf] are not finite - try decreasing feature/sample_weight magnitudes";
+        case RFM_ERR_NONFINITE + 5: return "item-feature factors [v_if] are not finite - try decreasing feature/sample_weight magnitudes";
+        default: return "unknown status";
+    }
+}
+
+int rfm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int rfm_fit_supported(const rfm_fit_config *cfg) { return validate(cfg); }
+
+size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
+    if (validate(cfg) != RFM_OK) return 0;
+    return carve(nullptr, cfg->epochs, cfg->max_samples).bytes;
+}
+
+int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
+    int rc = validate(cfg);
+    if (rc != RFM_OK) return rc;
+    if (!b || !b->interactions || !b->sample_weight || !b->csr_offsets || !b->csr_items || !b->x_uf || !b->x_if ||
+        !b->w_i || !b->w_if || !b->v_u || !b->v_i || !b->v_uf || !b->v_if)
+        return RFM_ERR_BAD_ARG;
+    if (cfg->rng == RFM_RNG_MT19937 && !b->perms && cfg->n_interactions > 0) return RFM_ERR_BAD_ARG;
+    if ((rc = device_ok()) != RFM_OK) return rc;
+    const int E = cfg->epochs;
+    const int64_t N = cfg->n_interactions;
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples);
+    if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const ShapeEntry *shape = pick_shape(cfg->n_factors);
+    const bool serial = cfg->mode == RFM_MODE_SERIAL;
+    const bool feat = cfg->has_user_features || cfg->has_item_features;
+    const sgd_launch_fn launch = shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
+
+    // ---- host-side constants: WARP multipliers in double like the reference (integer division inside the log,
+    //      rankfm/_rankfm.pyx:269 under cdivision=True), MT19937 seeding (mt19937ar.c:60-73)
+    std::vector<float> mult((size_t)cfg->max_samples + 1, 0.0f);
+    for (int s = 1; s <= cfg->max_samples; ++s)
+        mult[s] = (float)(log((double)((cfg->n_items - 1) / s)) / log((double)cfg->n_items));
+    RFM_HIP(hipMemsetAsync(b->workspace, 0, ws.bytes, stream));
+    RFM_HIP(hipMemcpyAsync(ws.multiplier, mult.data(), mult.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    std::vector<uint32_t> mt(625);
+    if (cfg->rng == RFM_RNG_MT19937) {
+        mt[0] = cfg->seed;
+        for (int k = 1; k < 624; ++k) mt[k] = 1812433253u * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (uint32_t)k;
+        mt[624] = 624;
+        RFM_HIP(hipMemcpyAsync(ws.mt_state, mt.data(), 625 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    }
+    degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, cfg->n_users,
+                                                                                      cfg->n_items, ws.error_flags);
+
+    // ---- launch geometry
+    const int rows_per_wave = serial ? 1 : 64 / shape->group;
+    int grid = 1;
+    int64_t rows_per_launch = N > 0 ? N : 1;
+    if (!serial) {
+        if (cfg->rows_per_launch > 0 && cfg->rows_per_launch < rows_per_launch) rows_per_launch = cfg->rows_per_launch;
+        const int64_t rows_per_block = (int64_t)rows_per_wave * 4;
+        const int64_t need = (rows_per_launch + rows_per_block - 1) / rows_per_block;
+        const int64_t cap = cfg->n_workgroups > 0 ? cfg->n_workgroups : (int64_t)(g_sm_count > 0 ? g_sm_count : 256) * 8;
+        grid = (int)(need < cap ? need : cap);
+        if (grid < 1) grid = 1;
+    }
+    const int launches = (int)((N + rows_per_launch - 1) / rows_per_launch);
+
+    std::vector<hipEvent_t> ev((size_t)2 * E, nullptr);
+    const bool timing = rep && rep->sgd_kernel_ms;
+    if (timing)
+        for (auto &e : ev) RFM_HIP(hipEventCreate(&e));
+
+    for (int e = 0; e < E; ++e) {
+        const int epoch = cfg->epoch_begin + e;
+        SgdArgs a;
+        a.interactions = b->interactions; a.sample_weight = b->sample_weight;
+        a.csr_off = b->csr_offsets; a.csr_items = b->csr_items; a.x_uf = b->x_uf; a.x_if = b->x_if;
+        a.w_i = b->w_i; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
+        a.perm = b->perms ? b->perms + (size_t)e * N : nullptr;
+        a.multiplier = ws.multiplier; a.mt_state = ws.mt_state;
+        a.ll = ws.ll + e; a.draws = ws.draws + e; a.error_flags = ws.error_flags;
+        a.n_rows = N; a.n_items = cfg->n_items; a.n_uf = cfg->n_user_features; a.n_if = cfg->n_item_features;
+        a.n_factors = cfg->n_factors; a.has_uf = cfg->has_user_features; a.has_if = cfg->has_item_features;
+        a.max_samples = cfg->max_samples; a.rng = cfg->rng;
+        a.epoch_key = rfm_epoch_key(cfg->seed, (uint32_t)epoch);
+        a.perm_bits = rfm_perm_bits((uint32_t)N);
+        // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
+        a.eta = cfg->learning_schedule == RFM_SCHEDULE_CONSTANT
+                    ? cfg->learning_rate
+                    : (float)((double)cfg->learning_rate / pow((double)(epoch + 1), (double)cfg->learning_exponent));
+        a.reg_a = 2.0f * cfg->alpha;      // :171
+        a.reg_b = 2.0f * cfg->beta;       // :172
+
+        if (timing) RFM_HIP(hipEventRecord(ev[2 * e], stream));
+        for (int64_t p0 = 0; p0 < N; p0 += rows_per_launch) {
+            a.pos_begin = p0;
+            a.pos_end = p0 + rows_per_launch < N ? p0 + rows_per_launch : N;
+            launch(a, grid, stream);
+        }
+        if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));
+
+        if (cfg->check_finite || cfg->want_penalty) {
+            TailArgs t;
+            const float *ptrs[6] = {b->w_i, b->w_if, b->v_u, b->v_i, b->v_uf, b->v_if};
+            const unsigned long long lens[6] = {
+                (unsigned long long)cfg->n_items, (unsigned long long)cfg->n_item_features,
+                (unsigned long long)cfg->n_users * cfg->n_factors, (unsigned long long)cfg->n_items * cfg->n_factors,
+                (unsigned long long)cfg->n_user_features * cfg->n_factors,
+                (unsigned long long)cfg->n_item_features * cfg->n_factors};
+            unsigned long long total = 0;
+            for (int k = 0; k < 6; ++k) { t.ptr[k] = ptrs[k]; t.len[k] = lens[k]; total += lens[k]; }
+            t.sumsq = ws.sumsq + 6 * e;
+            t.nonfinite = ws.nonfinite + e;
+            int tgrid = (int)((total / 4 + 255) / 256);
+            if (tgrid > 512) tgrid = 512;
+            if (tgrid < 1) tgrid = 1;
+            if (cfg->want_penalty) tail_kernel<true><<<dim3(tgrid), dim3(256), 0, stream>>>(t);
+            else tail_kernel<false><<<dim3(tgrid), dim3(256), 0, stream>>>(t);
+        }
+    }
+    RFM_HIP(hipGetLastError());
+
+    // ---- one synchronisation: bring the per-epoch results back
+    std::vector<double> h_ll(E), h_sumsq((size_t)6 * E);
+    std::vector<unsigned long long> h_draws(E);
+    std::vector<unsigned int> h_nonfinite(E);
+    unsigned int h_err[4] = {0, 0, 0, 0};
+    RFM_HIP(hipMemcpyAsync(h_ll.data(), ws.ll, sizeof(double) * E, hipMemcpyDeviceToHost, stream));
+    RFM_HIP(hipMemcpyAsync(h_draws.data(), ws.draws, sizeof(unsigned long long) * E, hipMemcpyDeviceToHost, stream));
+    RFM_HIP(hipMemcpyAsync(h_sumsq.data(), ws.sumsq, sizeof(double) * 6 * E, hipMemcpyDeviceToHost, stream));
+    RFM_HIP(hipMemcpyAsync(h_nonfinite.data(), ws.nonfinite, sizeof(unsigned int) * E, hipMemcpyDeviceToHost, stream));
+    RFM_HIP(hipMemcpyAsync(h_err, ws.error_flags, sizeof(h_err), hipMemcpyDeviceToHost, stream));
+    RFM_HIP(hipStreamSynchronize(stream));
+
+    int status = RFM_OK;
+    int epochs_done = E, bad_array = -1;
+    if (h_err[0] & 3u) status = RFM_ERR_USER_SATURATED;
+    for (int e = 0; e < E && status == RFM_OK; ++e) {
+        if (cfg->check_finite && h_nonfinite[e]) {
+            for (int k = 0; k < 6; ++k)
+                if (h_nonfinite[e] & (1u << k)) { bad_array = k; break; }    // first in assert_finite order
+            status = RFM_ERR_NONFINITE + bad_array;
+            epochs_done = e;
+        }
+    }
+    if (rep) {
+        for (int e = 0; e < E; ++e) {
+            if (rep->log_likelihood) rep->log_likelihood[e] = h_ll[e];
+            if (rep->n_draws) rep->n_draws[e] = (int64_t)h_draws[e];
+            if (rep->reg_penalty) {
+                const double *s = &h_sumsq[(size_t)6 * e];
+                rep->reg_penalty[e] = (double)cfg->alpha * (s[0] + s[2] + s[3]) + (double)cfg->beta * (s[1] + s[4] + s[5]);
+            }
+            if (timing) {
+                float ms = 0.0f;
+                hipEventElapsedTime(&ms, ev[2 * e], ev[2 * e + 1]);
+                rep->sgd_kernel_ms[e] = ms;
+            }
+        }
+        rep->epochs_done = epochs_done;
+        rep->nonfinite_array = bad_array;
+        rep->launches_per_epoch = launches;
+        rep->waves_per_launch = grid * (serial ? 1 : 4);
+    }
+    if (timing)
+        for (auto &e : ev) hipEventDestroy(e);
+    return status;
+}
+
+int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device, rfm_fit_report *rep) {
+    int rc = validate(cfg);
+    if (rc != RFM_OK) return rc;
+    if (!h || !h->interactions || !h->sample_weight || !h->csr_offsets || !h->csr_items || !h->x_uf || !h->x_if ||
+        !h->w_i || !h->w_if || !h->v_u || !h->v_i || !h->v_uf || !h->v_if)
+        return RFM_ERR_BAD_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1 || device < 0 || device >= n_dev) {
+        g_last_error = "no HIP device visible";
+        return RFM_ERR_NO_DEVICE;
+    }
+    RFM_HIP(hipSetDevice(device));
+    const int64_t N = cfg->n_interactions;
+    const size_t U = cfg->n_users, I = cfg->n_items, P = cfg->n_user_features, Q = cfg->n_item_features, F = cfg->n_factors;
+    const size_t nnz = (size_t)h->csr_offsets[U];
+    struct Item { const void *src; void **dst; size_t bytes; bool out; };
+    rfm_fit_buffers d;
+    memset(&d, 0, sizeof d);
+    const size_t ws_bytes = rfm_fit_workspace_bytes(cfg);
+    Item items[] = {
+        {h->interactions, (void **)&d.interactions, sizeof(int32_t) * 2 * (size_t)N, false},
+        {h->sample_weight, (void **)&d.sample_weight, sizeof(float) * (size_t)N, false},
+        {h->csr_offsets, (void **)&d.csr_offsets, sizeof(int64_t) * (U + 1), false},
+        {h->csr_items, (void **)&d.csr_items, sizeof(int32_t) * nnz, false},
+        {h->x_uf, (void **)&d.x_uf, sizeof(float) * U * P, false},
+        {h->x_if, (void **)&d.x_if, sizeof(float) * I * Q, false},
+        {h->w_i, (void **)&d.w_i, sizeof(float) * I, true},
+        {h->w_if, (void **)&d.w_if, sizeof(float) * Q, true},
+        {h->v_u, (void **)&d.v_u, sizeof(float) * U * F, true},
+        {h->v_i, (void **)&d.v_i, sizeof(float) * I * F, true},
+        {h->v_uf, (void **)&d.v_uf, sizeof(float) * P * F, true},
+        {h->v_if, (void **)&d.v_if, sizeof(float) * Q * F, true},
+        {h->perms, (void **)&d.perms, h->perms ? sizeof(int32_t) * (size_t)N * cfg->epochs : 0, false},
+        {nullptr, &d.workspace, ws_bytes, false},
+    };
+    std::vector<void *> allocated;
+    auto cleanup = [&]() { for (void *p : allocated) hipFree(p); };
+    for (Item &it : items) {
+        if (it.bytes == 0 && it.dst != (void **)&d.csr_items && it.dst != (void **)&d.interactions &&
+            it.dst != (void **)&d.sample_weight) { *it.dst = nullptr; continue; }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, it.bytes ? it.bytes : 16);
+        if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMalloc"); }
+        allocated.push_back(p);
+        *it.dst = p;
+        if (it.src && it.bytes) {
+            e = hipMemcpy(p, it.src, it.bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy H2D"); }
+        }
+    }
+    d.workspace_bytes = ws_bytes;
+    rc = rfm_fit_device(cfg, &d, nullptr, rep);
+    // the reference mutates the weights in place; on a non-finite epoch it has done so too (rankfm/_rankfm.pyx:329)
+    if (rc == RFM_OK || rc >= RFM_ERR_NONFINITE) {
+        for (Item &it : items) {
+            if (!it.out) continue;
+            hipError_t e = hipMemcpy(const_cast<void *>(it.src), *it.dst, it.bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy D2H"); }
+        }
+    }
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

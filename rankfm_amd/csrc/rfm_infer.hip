@@ -1,0 +1,276 @@
+// rfm_infer.hip -- `_predict` and `_recommend` on the device (the callers either side of the training path).
+//
+//   rfm_predict_*    replaces rankfm/_rankfm.pyx:345-390  (score arbitrary (u,i) pairs, NaN for unknown ids)
+//   rfm_recommend_*  replaces rankfm/_rankfm.pyx:393-460  (score all items per user, rank descending, optionally
+//                    skip the user's observed items, keep the first n_items)
+//
+// Both reuse the pointwise utility of compute_ui_utility (rankfm/_rankfm.pyx:48-89) in the factored form
+//   U(u,i) = w_i[i] + x_if[i].w_if + < v_u[u] + x_uf[u].v_uf , v_i[i] > + < x_if[i].v_if , v_u[u] >
+// evaluated by 16-lane groups with lanes striding the factor dimension (coalesced row reads).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "../../include/rankfm_hip.h"
+
+namespace rfm {
+
+constexpr int kGroup = 16;
+
+__device__ __forceinline__ float group16_sum(float x) {
+#pragma unroll
+    for (int m = kGroup / 2; m > 0; m >>= 1) x += __shfl_xor(x, m);
+    return x;
+}
+
+// utility of (u, i); all 16 lanes of the group call it with the same (u, i) and get the same value
+__device__ __forceinline__ float utility16(const rfm_model_view &m, int u, int i, int sub) {
+    const int F = m.n_factors;
+    const float *vu = m.v_u + (size_t)u * F, *vi = m.v_i + (size_t)i * F;
+    float part = 0.0f;
+    for (int f = sub; f < F; f += kGroup) {
+        float eu = vu[f], bi = 0.0f;
+        if (m.has_user_features) {
+            const float *xu = m.x_uf + (size_t)u * m.n_user_features;
+            for (int p = 0; p < m.n_user_features; ++p) {
+                const float x = xu[p];
+                if (x != 0.0f) eu += x * m.v_uf[(size_t)p * F + f];
+            }
+        }
+        if (m.has_item_features) {
+            const float *xi = m.x_if + (size_t)i * m.n_item_features;
+            for (int q = 0; q < m.n_item_features; ++q) {
+                const float x = xi[q];
+                if (x != 0.0f) bi += x * m.v_if[(size_t)q * F + f];
+            }
+        }
+        part += eu * vi[f] + bi * vu[f];
+    }
+    float res = m.w_i[i] + group16_sum(part);
+    if (m.has_item_features) {
+        const float *xi = m.x_if + (size_t)i * m.n_item_features;
+        float s = 0.0f;
+        for (int q = sub; q < m.n_item_features; q += kGroup) s += xi[q] * m.w_if[q];
+        res += group16_sum(s);
+    }
+    return res;
+}
+
+__global__ void __launch_bounds__(256) predict_kernel(const rfm_model_view m, long long n_pairs,
+                                                      const float *__restrict__ pairs, float *__restrict__ scores) {
+    const int sub = threadIdx.x & (kGroup - 1);
+    const long long group = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    const long long n_groups = ((long long)gridDim.x * blockDim.x) / kGroup;
+    for (long long r = group; r < n_pairs; r += n_groups) {
+        const float uf = pairs[2 * r], itf = pairs[2 * r + 1];
+        float s;
+        if (isnan(uf) || isnan(itf)) s = __uint_as_float(0x7fc00000u);   // rankfm/_rankfm.pyx:380-381
+        else s = utility16(m, (int)uf, (int)itf, sub);
+        if (sub == 0) scores[r] = s;
+    }
+}
+
+// scores[slot, i] for a chunk of users; blockIdx.y = user slot
+__global__ void __launch_bounds__(256) user_scores_kernel(const rfm_model_view m, const float *__restrict__ users,
+                                                          long long user_begin, float *__restrict__ scores) {
+    const long long slot = blockIdx.y;
+    const float uf = users[user_begin + slot];
+    if (isnan(uf)) return;
+    const int u = (int)uf;
+    const int sub = threadIdx.x & (kGroup - 1);
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    const int n_groups = (gridDim.x * blockDim.x) / kGroup;
+    float *out = scores + (size_t)slot * m.n_items;
+    for (int i = group; i < m.n_items; i += n_groups) {
+        const float s = utility16(m, u, i, sub);
+        if (sub == 0) out[i] = s;
+    }
+}
+
+// one block per user slot: optionally knock out the user's observed items, then n_rec rounds of block-wide argmax.
+// Ranking is descending by utility; equal scores may come out in any order (np.argsort in the reference is
+// unstable too, rankfm/_rankfm.pyx:444).
+__global__ void __launch_bounds__(256) topn_kernel(const float *__restrict__ users, long long user_begin, int n_items,
+                                                   const int64_t *__restrict__ csr_off, const int32_t *__restrict__ csr_items,
+                                                   int filter_previous, int n_rec, float *__restrict__ scores,
+                                                   float *__restrict__ rec) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    const long long slot = blockIdx.x;
+    const float uf = users[user_begin + slot];
+    float *out = rec + (size_t)(user_begin + slot) * n_rec;
+    if (isnan(uf)) {                                                      // rankfm/_rankfm.pyx:435-437
+        for (int k = threadIdx.x; k < n_rec; k += blockDim.x) out[k] = __uint_as_float(0x7fc00000u);
+        return;
+    }
+    const int u = (int)uf;
+    float *row = scores + (size_t)slot * n_items;
+    const float kRemoved = -INFINITY;
+    if (filter_previous) {                                                // rankfm/_rankfm.pyx:450-451
+        for (int64_t k = csr_off[u] + threadIdx.x; k < csr_off[u + 1]; k += blockDim.x) row[csr_items[k]] = kRemoved;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int r = 0; r < n_rec; ++r) {
+        float best = -INFINITY;
+        int best_i = -1;
+        for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+            const float v = row[i];
+            // NaN scores never win; among equals the larger index wins, like a reversed ascending sort
+            if (v > best || (v == best && v > kRemoved && i > best_i)) { best = v; best_i = i; }
+        }
+#pragma unroll
+        for (int msk = 32; msk > 0; msk >>= 1) {
+            const float ov = __shfl_xor(best, msk);
+            const int oi = __shfl_xor(best_i, msk);
+            if (oi >= 0 && (ov > best || (ov == best && oi > best_i))) { best = ov; best_i = oi; }
+        }
+        if (lane == 0) { s_val[wid] = best; s_idx[wid] = best_i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float b = s_val[0];
+            int bi = s_idx[0];
+            for (int w = 1; w < 4; ++w)
+                if (s_idx[w] >= 0 && (s_val[w] > b || (s_val[w] == b && s_idx[w] > bi))) { b = s_val[w]; bi = s_idx[w]; }
+            out[r] = bi >= 0 ? (float)bi : __uint_as_float(0x7fc00000u);
+            if (bi >= 0) row[bi] = kRemoved;
+        }
+        __syncthreads();
+    }
+}
+
+static thread_local char g_infer_err[256];
+
+static int check_model(const rfm_model_view *m) {
+    if (!m || m->n_users < 1 || m->n_items < 1 || m->n_factors < 1 || m->n_user_features < 1 || m->n_item_features < 1)
+        return RFM_ERR_BAD_ARG;
+    if (!m->x_uf || !m->x_if || !m->w_i || !m->w_if || !m->v_u || !m->v_i || !m->v_uf || !m->v_if) return RFM_ERR_BAD_ARG;
+    return RFM_OK;
+}
+
+static size_t model_bytes(const rfm_model_view *m, int k) {
+    const size_t U = m->n_users, I = m->n_items, P = m->n_user_features, Q = m->n_item_features, F = m->n_factors;
+    const size_t n[8] = {U * P, I * Q, I, Q, U * F, I * F, P * F, Q * F};
+    return n[k] * sizeof(float);
+}
+
+// upload a host model view; returns device view + list of allocations
+static int upload_model(const rfm_model_view *h, rfm_model_view *d, void *allocs[8]) {
+    *d = *h;
+    const float *src[8] = {h->x_uf, h->x_if, h->w_i, h->w_if, h->v_u, h->v_i, h->v_uf, h->v_if};
+    const float **dst[8] = {&d->x_uf, &d->x_if, &d->w_i, &d->w_if, &d->v_u, &d->v_i, &d->v_uf, &d->v_if};
+    for (int k = 0; k < 8; ++k) allocs[k] = nullptr;
+    for (int k = 0; k < 8; ++k) {
+        const size_t bytes = model_bytes(h, k);
+        if (hipMalloc(&allocs[k], bytes) != hipSuccess) return RFM_ERR_HIP;
+        if (hipMemcpy(allocs[k], src[k], bytes, hipMemcpyHostToDevice) != hipSuccess) return RFM_ERR_HIP;
+        *dst[k] = (const float *)allocs[k];
+    }
+    return RFM_OK;
+}
+
+static void free_all(void **p, int n) {
+    for (int k = 0; k < n; ++k)
+        if (p[k]) hipFree(p[k]);
+}
+
+constexpr long long kRecommendChunk = 1024;   // users scored per pass (workspace = chunk * n_items floats)
+
+}  // namespace rfm
+
+using namespace rfm;
+
+extern "C" {
+
+int rfm_predict_device(const rfm_model_view *m, int64_t n_pairs, const float *pairs, float *scores, void *hip_stream) {
+    int rc = check_model(m);
+    if (rc != RFM_OK) return rc;
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !scores))) return RFM_ERR_BAD_ARG;
+    if (n_pairs == 0) return RFM_OK;
+    long long blocks = (n_pairs * kGroup + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    predict_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream>>>(*m, (long long)n_pairs, pairs, scores);
+    return hipGetLastError() == hipSuccess ? RFM_OK : RFM_ERR_HIP;
+}
+
+int rfm_predict_host(const rfm_model_view *hm, int64_t n_pairs, const float *pairs, float *scores, int device) {
+    int rc = check_model(hm);
+    if (rc != RFM_OK) return rc;
+    if (n_pairs < 0 || (n_pairs > 0 && (!pairs || !scores))) return RFM_ERR_BAD_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RFM_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RFM_ERR_HIP;
+    if (n_pairs == 0) return RFM_OK;
+    rfm_model_view dm;
+    void *allocs[10] = {nullptr};
+    rc = upload_model(hm, &dm, allocs);
+    if (rc == RFM_OK && (hipMalloc(&allocs[8], sizeof(float) * 2 * n_pairs) != hipSuccess ||
+                         hipMalloc(&allocs[9], sizeof(float) * n_pairs) != hipSuccess)) rc = RFM_ERR_HIP;
+    if (rc == RFM_OK && hipMemcpy(allocs[8], pairs, sizeof(float) * 2 * n_pairs, hipMemcpyHostToDevice) != hipSuccess) rc = RFM_ERR_HIP;
+    if (rc == RFM_OK) rc = rfm_predict_device(&dm, n_pairs, (const float *)allocs[8], (float *)allocs[9], nullptr);
+    if (rc == RFM_OK && hipMemcpy(scores, allocs[9], sizeof(float) * n_pairs, hipMemcpyDeviceToHost) != hipSuccess) rc = RFM_ERR_HIP;
+    free_all(allocs, 10);
+    return rc;
+}
+
+size_t rfm_recommend_workspace_bytes(const rfm_model_view *m, int64_t n_rec_users, int32_t n_rec) {
+    if (check_model(m) != RFM_OK || n_rec_users < 0 || n_rec < 1) return 0;
+    const long long chunk = n_rec_users < kRecommendChunk ? (n_rec_users > 0 ? n_rec_users : 1) : kRecommendChunk;
+    return sizeof(float) * (size_t)chunk * (size_t)m->n_items;
+}
+
+int rfm_recommend_device(const rfm_model_view *m, int64_t n_users, const float *users, const int64_t *csr_off,
+                         const int32_t *csr_items, int32_t n_rec, int32_t filter_previous, float *rec, void *workspace,
+                         size_t workspace_bytes, void *hip_stream) {
+    int rc = check_model(m);
+    if (rc != RFM_OK) return rc;
+    if (n_users < 0 || n_rec < 1 || n_rec > m->n_items) return RFM_ERR_BAD_ARG;
+    if (n_users == 0) return RFM_OK;
+    if (!users || !rec || (filter_previous && (!csr_off || !csr_items))) return RFM_ERR_BAD_ARG;
+    if (!workspace || workspace_bytes < rfm_recommend_workspace_bytes(m, n_users, n_rec)) return RFM_ERR_WORKSPACE;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    float *scores = (float *)workspace;
+    const long long chunk = n_users < kRecommendChunk ? n_users : kRecommendChunk;
+    int gx = (m->n_items * kGroup + 255) / 256;
+    if (gx > 64) gx = 64;
+    for (long long u0 = 0; u0 < n_users; u0 += chunk) {
+        const long long nu = (n_users - u0) < chunk ? (n_users - u0) : chunk;
+        user_scores_kernel<<<dim3(gx, (unsigned)nu), dim3(256), 0, stream>>>(*m, users, u0, scores);
+        topn_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, m->n_items, csr_off, csr_items, filter_previous,
+                                                                   n_rec, scores, rec);
+    }
+    return hipGetLastError() == hipSuccess ? RFM_OK : RFM_ERR_HIP;
+}
+
+int rfm_recommend_host(const rfm_model_view *hm, int64_t n_users, const float *users, const int64_t *csr_off,
+                       const int32_t *csr_items, int32_t n_rec, int32_t filter_previous, float *rec, int device) {
+    int rc = check_model(hm);
+    if (rc != RFM_OK) return rc;
+    if (n_users < 0 || n_rec < 1 || n_rec > hm->n_items) return RFM_ERR_BAD_ARG;
+    if (n_users > 0 && (!users || !rec || !csr_off || !csr_items)) return RFM_ERR_BAD_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RFM_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RFM_ERR_HIP;
+    if (n_users == 0) return RFM_OK;
+    rfm_model_view dm;
+    void *allocs[13] = {nullptr};
+    rc = upload_model(hm, &dm, allocs);
+    const size_t nnz = (size_t)csr_off[hm->n_users];
+    const size_t ws = rfm_recommend_workspace_bytes(hm, n_users, n_rec);
+    const size_t sizes[5] = {sizeof(float) * n_users, sizeof(int64_t) * ((size_t)hm->n_users + 1),
+                             sizeof(int32_t) * (nnz ? nnz : 1), sizeof(float) * n_users * n_rec, ws};
+    const void *srcs[5] = {users, csr_off, csr_items, nullptr, nullptr};
+    for (int k = 0; k < 5 && rc == RFM_OK; ++k) {
+        if (hipMalloc(&allocs[8 + k], sizes[k]) != hipSuccess) rc = RFM_ERR_HIP;
+        else if (srcs[k] && hipMemcpy(allocs[8 + k], srcs[k], k == 2 ? sizeof(int32_t) * nnz : sizes[k], hipMemcpyHostToDevice) != hipSuccess)
+            rc = RFM_ERR_HIP;
+    }
+    if (rc == RFM_OK)
+        rc = rfm_recommend_device(&dm, n_users, (const float *)allocs[8], (const int64_t *)allocs[9], (const int32_t *)allocs[10],
+                                  n_rec, filter_previous, (float *)allocs[11], allocs[12], ws, nullptr);
+    if (rc == RFM_OK && hipMemcpy(rec, allocs[11], sizes[3], hipMemcpyDeviceToHost) != hipSuccess) rc = RFM_ERR_HIP;
+    free_all(allocs, 13);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,6 @@
+// SGD kernel instantiations for row-group shape VEC=1, G=16, KPL=1 (see rfm_sgd.hpp)
+#define RFM_VEC 1
+#define RFM_G 16
+#define RFM_KPL 1
+#define RFM_SHAPE_FN sgd_table_v1_g16_k1
+#include "rfm_sgd_inst.inc"

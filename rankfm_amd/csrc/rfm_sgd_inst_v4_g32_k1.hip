@@ -1,0 +1,6 @@
+// SGD kernel instantiations for row-group shape VEC=4, G=32, KPL=1 (see rfm_sgd.hpp)
+#define RFM_VEC 4
+#define RFM_G 32
+#define RFM_KPL 1
+#define RFM_SHAPE_FN sgd_table_v4_g32_k1
+#include "rfm_sgd_inst.inc"

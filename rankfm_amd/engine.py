@@ -1,0 +1,107 @@
+"""Device-resident training session: the model and the interaction shard stay in HBM between calls.
+
+`_rankfm._fit` (the drop-in boundary) uploads, trains and downloads on every call, which is what the reference's
+call site expects.  Long jobs, the benchmark and the multi-GPU trainer instead keep everything resident as
+torch tensors (PyTorch is used for device memory and streams only) and call `rfm_fit_device` on raw pointers.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip
+
+WEIGHT_NAMES = ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")
+
+
+class DeviceSession:
+    def __init__(self, interactions, sample_weight, csr_offsets, csr_items, x_uf, x_if, weights, *, alpha=0.01, beta=0.1,
+                 learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25, max_samples=1,
+                 mode="hogwild", rng="counter", seed=1492, device=None, n_workgroups=0, rows_per_launch=0,
+                 check_finite=True, want_penalty=False, has_user_features=None, has_item_features=None):
+        if not torch.cuda.is_available():
+            raise _hip.EngineUnavailable("no MI355X visible to PyTorch-ROCm: rankfm_amd has no CPU fallback")
+        _hip.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if learning_schedule not in ("constant", "invscaling"):
+            raise ValueError("unknown [learning_schedule]")
+        dev = self.device
+
+        def up(a, dtype):
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=dtype).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dtype)
+
+        self.interactions = up(interactions, torch.int32)
+        self.sample_weight = up(sample_weight, torch.float32)
+        self.csr_offsets = up(csr_offsets, torch.int64)
+        self.csr_items = up(csr_items, torch.int32)
+        self.x_uf = up(x_uf, torch.float32)
+        self.x_if = up(x_if, torch.float32)
+        self.weights = {k: up(weights[k], torch.float32) for k in WEIGHT_NAMES}
+        self.n_interactions = int(self.interactions.shape[0])
+        self.n_users, self.n_factors = (int(s) for s in self.weights["v_u"].shape)
+        self.n_items = int(self.weights["v_i"].shape[0])
+        self.n_user_features = int(self.weights["v_uf"].shape[0])
+        self.n_item_features = int(self.weights["v_if"].shape[0])
+        self.has_uf = int(bool((self.x_uf != 0).any().item())) if has_user_features is None else int(has_user_features)
+        self.has_if = int(bool((self.x_if != 0).any().item())) if has_item_features is None else int(has_item_features)
+        self.hyper = dict(alpha=alpha, beta=beta, learning_rate=learning_rate,
+                          learning_schedule=_hip.SCHEDULE_CONSTANT if learning_schedule == "constant" else _hip.SCHEDULE_INVSCALING,
+                          learning_exponent=learning_exponent, max_samples=int(max_samples))
+        self.mode = _hip.MODE_SERIAL if mode == "serial" else _hip.MODE_HOGWILD
+        self.rng = _hip.RNG_MT19937 if rng == "mt19937" else _hip.RNG_COUNTER
+        self.seed = int(seed) & 0xFFFFFFFF
+        self.n_workgroups, self.rows_per_launch = int(n_workgroups), int(rows_per_launch)
+        self.check_finite, self.want_penalty = int(check_finite), int(want_penalty)
+        self._workspace = None
+
+    def _config(self, epochs, epoch_begin):
+        return _hip.FitConfig(
+            n_interactions=self.n_interactions, n_users=self.n_users, n_items=self.n_items,
+            n_user_features=self.n_user_features, n_item_features=self.n_item_features, n_factors=self.n_factors,
+            has_user_features=self.has_uf, has_item_features=self.has_if,
+            epochs=int(epochs), epoch_begin=int(epoch_begin), mode=self.mode, rng=self.rng, seed=self.seed,
+            check_finite=self.check_finite, want_penalty=self.want_penalty,
+            n_workgroups=self.n_workgroups, rows_per_launch=self.rows_per_launch, **self.hyper)
+
+    def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True):
+        """train `epochs` epochs in place on the resident tensors; returns the per-epoch report (numpy arrays)"""
+        cfg = self._config(epochs, epoch_begin)
+        need = _hip.lib().rfm_fit_workspace_bytes(C.byref(cfg))
+        if need == 0:
+            _hip.raise_for_status(_hip.lib().rfm_fit_supported(C.byref(cfg)))
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        perms_t = None
+        if perms is not None:
+            perms_t = torch.as_tensor(np.ascontiguousarray(perms, dtype=np.int32)).to(self.device)
+            assert tuple(perms_t.shape) == (epochs, self.n_interactions)
+        w = self.weights
+        buf = _hip.FitBuffers(
+            interactions=self.interactions.data_ptr(), sample_weight=self.sample_weight.data_ptr(),
+            csr_offsets=self.csr_offsets.data_ptr(), csr_items=self.csr_items.data_ptr(),
+            x_uf=self.x_uf.data_ptr(), x_if=self.x_if.data_ptr(),
+            w_i=w["w_i"].data_ptr(), w_if=w["w_if"].data_ptr(), v_u=w["v_u"].data_ptr(), v_i=w["v_i"].data_ptr(),
+            v_uf=w["v_uf"].data_ptr(), v_if=w["v_if"].data_ptr(),
+            perms=perms_t.data_ptr() if perms_t is not None else None,
+            workspace=self._workspace.data_ptr(), workspace_bytes=self._workspace.numel())
+        ll = np.zeros(epochs, dtype=np.float64)
+        pen = np.zeros(epochs, dtype=np.float64)
+        ms = np.zeros(epochs, dtype=np.float32)
+        draws = np.zeros(epochs, dtype=np.int64)
+        rep = _hip.FitReport(
+            log_likelihood=ll.ctypes.data_as(C.POINTER(C.c_double)), reg_penalty=pen.ctypes.data_as(C.POINTER(C.c_double)),
+            sgd_kernel_ms=ms.ctypes.data_as(C.POINTER(C.c_float)), n_draws=draws.ctypes.data_as(C.POINTER(C.c_int64)))
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = _hip.lib().rfm_fit_device(C.byref(cfg), C.byref(buf), C.c_void_p(stream), C.byref(rep))
+        out = dict(status=rc, log_likelihood=ll, reg_penalty=pen, sgd_kernel_ms=ms, n_draws=draws,
+                   epochs_done=rep.epochs_done, launches_per_epoch=rep.launches_per_epoch,
+                   waves_per_launch=rep.waves_per_launch)
+        if raise_on_error:
+            _hip.raise_for_status(rc)
+        return out
+
+    def weights_to_host(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.weights.items()}

@@ -1,0 +1,187 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI, against (a) the golden vectors minted by the
+reference's own `_fit` and (b) the CPU oracle on the same seeded inputs.
+
+Tolerances (fp32; stated per check):
+  serial mode vs reference golden / oracle ... 2e-5 abs + 1e-4 rel on every weight.  Same visiting order, same
+      negatives, same update order; the residue is summation order (xor-butterfly vs sequential dot product, the
+      reference's own -ffast-math) and fp32 __expf vs double exp.
+  hogwild mode vs oracle ..................... statistical: Frobenius norms within 2 %, per-epoch log-likelihood
+      within 2 %, weight-wise correlation > 0.98 (thousands of wavefronts apply stale-read atomic updates; bit
+      parity is impossible by construction, SURVEY.md §7 "hard parts").
+"""
+import numpy as np
+import pytest
+
+from conftest import WEIGHTS, golden_fit_cases, load_golden
+
+pytestmark = pytest.mark.gpu
+
+SERIAL_ATOL, SERIAL_RTOL = 2e-5, 1e-4
+S_SHUF = 12      # tests/golden/make_golden.py: np.random.seed(S_SHUF) right before the reference's _fit
+
+
+def _fit_from_golden(g, engine, epochs=None, report=None, verbose=False):
+    from rankfm_amd._rankfm import UserItemsCSR, _fit
+    w = {k: g["init_" + k].copy() for k in WEIGHTS}
+    epochs = int(g["epochs"]) if epochs is None else epochs
+    _fit(g["interactions"], g["sample_weight"], UserItemsCSR(g["csr_off"], g["csr_items"]), g["x_uf"], g["x_if"],
+         w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"],
+         float(g["alpha"]), float(g["beta"]), float(g["learning_rate"]), str(g["learning_schedule"]),
+         float(g["learning_exponent"]), int(g["max_samples"]), epochs, verbose, engine=engine, report=report)
+    return w
+
+
+@pytest.mark.parametrize("case", golden_fit_cases())
+def test_serial_mt_reproduces_reference_fit(case):
+    """REFERENCE_ENGINE = one wavefront, MT19937(1492), numpy shuffle: must land on the reference's final weights"""
+    from rankfm_amd import REFERENCE_ENGINE
+    from rankfm_amd._rankfm import numpy_epoch_permutations
+    g = load_golden("fit", case)
+    np.random.seed(S_SHUF)
+    assert np.array_equal(numpy_epoch_permutations(len(g["interactions"]), int(g["epochs"])), g["perms"])
+    np.random.seed(S_SHUF)
+    rep = {}
+    w = _fit_from_golden(g, REFERENCE_ENGINE, report=rep)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(w[k], g["final_" + k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg="%s:%s" % (case, k))
+    # printed value of the reference: round(LL - penalty, 2), LL accumulated in fp32 there
+    printed = rep["log_likelihood"] - rep["reg_penalty"]
+    np.testing.assert_allclose(printed, g["ll_printed"], rtol=2e-4, atol=0.02)
+    np.testing.assert_allclose(rep["reg_penalty"], g["reg_penalty"], rtol=1e-4)
+    # one epoch only
+    np.random.seed(S_SHUF)
+    w1 = _fit_from_golden(g, REFERENCE_ENGINE, epochs=1)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(w1[k], g["epoch1_" + k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL)
+
+
+@pytest.mark.parametrize("case", ["bpr_nofeat_const_f64", "warp_nofeat_inv_f64_sw", "warp_feat_inv_f12", "bpr_feat_const_f8",
+                                  "bpr_nofeat_inv_f10_sw"])
+def test_serial_counter_matches_oracle(oracle, case):
+    """same counter-based draws and on-the-fly permutation on both sides (include/rfm_rng.h)"""
+    from rankfm_amd import EngineOptions
+    g = load_golden("fit", case)
+    w = _fit_from_golden(g, EngineOptions(mode="serial", rng="counter", shuffle="device", seed=77))
+    o = {k: g["init_" + k].copy() for k in WEIGHTS}
+    oracle.fit(g["interactions"], g["sample_weight"], g["csr_off"], g["csr_items"], g["x_uf"], g["x_if"],
+               o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"], float(g["alpha"]), float(g["beta"]),
+               float(g["learning_rate"]), str(g["learning_schedule"]), float(g["learning_exponent"]),
+               int(g["max_samples"]), int(g["epochs"]), perms=None, rng_mode=oracle.RNG_COUNTER, seed=77, membership="binary")
+    for k in WEIGHTS:
+        np.testing.assert_allclose(w[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg="%s:%s" % (case, k))
+
+
+def _problem(U, I, N, F, seed, n_uf=0, n_if=0, sigma=0.1):
+    from rankfm_amd import synthetic
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=seed, zipf_s=1.0)
+    w = synthetic.init_weights(U, I, F, n_uf, n_if, sigma=sigma, seed=seed + 1)
+    x_uf = synthetic.make_features(U, n_uf, seed + 2) if n_uf else np.zeros((U, 1), np.float32)
+    x_if = synthetic.make_features(I, n_if, seed + 3) if n_if else np.zeros((I, 1), np.float32)
+    sw = np.ones(N, dtype=np.float32)
+    return pairs, csr, sw, x_uf, x_if, w
+
+
+def _both(oracle, prob, max_samples, epochs, seed=5, lr=0.1, engine_kw=None):
+    from rankfm_amd import EngineOptions
+    from rankfm_amd._rankfm import _fit
+    pairs, csr, sw, x_uf, x_if, w0 = prob
+    g = {k: v.copy() for k, v in w0.items()}
+    rep = {}
+    _fit(pairs, sw, csr, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"],
+         0.01, 0.1, lr, "constant", 0.25, max_samples, epochs, False,
+         engine=EngineOptions(mode="hogwild", seed=seed, **(engine_kw or {})), report=rep)
+    o = {k: v.copy() for k, v in w0.items()}
+    out = oracle.fit(pairs, sw, csr.offsets, csr.items, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"],
+                     0.01, 0.1, lr, "constant", 0.25, max_samples, epochs, perms=None, rng_mode=oracle.RNG_COUNTER,
+                     seed=seed, membership="binary")
+    return g, rep, o, out
+
+
+def _assert_statistical_parity(g, rep, o, out, names=("v_u", "v_i", "w_i"), norm_tol=0.02, ll_tol=0.02, corr=0.98):
+    for k in names:
+        ng, no = np.linalg.norm(g[k]), np.linalg.norm(o[k])
+        assert abs(ng - no) <= norm_tol * no, "%s norm %g vs oracle %g" % (k, ng, no)
+        c = np.corrcoef(g[k].ravel(), o[k].ravel())[0, 1]
+        assert c > corr, "%s correlation with the sequential oracle %.4f" % (k, c)
+    np.testing.assert_allclose(rep["log_likelihood"], out["ll"], rtol=ll_tol)
+
+
+@pytest.mark.parametrize("F", [64, 20, 10, 128])
+def test_hogwild_bpr_statistical_parity(oracle, F):
+    prob = _problem(U=4000, I=2500, N=200_000, F=F, seed=10 + F)
+    _assert_statistical_parity(*_both(oracle, prob, max_samples=1, epochs=3))
+
+
+def test_hogwild_warp_statistical_parity(oracle):
+    prob = _problem(U=4000, I=2500, N=200_000, F=64, seed=3, sigma=0.3)
+    g, rep, o, out = _both(oracle, prob, max_samples=20, epochs=3)
+    _assert_statistical_parity(g, rep, o, out)
+    assert rep["n_draws"].min() >= len(prob[0])      # at least one accepted draw per update
+
+
+def test_hogwild_features_statistical_parity(oracle):
+    prob = _problem(U=3000, I=2000, N=120_000, F=32, seed=21, n_uf=8, n_if=8)
+    g, rep, o, out = _both(oracle, prob, max_samples=1, epochs=2)
+    _assert_statistical_parity(g, rep, o, out, names=("v_u", "v_i", "w_i", "v_uf", "v_if", "w_if"), norm_tol=0.05, corr=0.95)
+
+
+def test_hogwild_conserves_item_factor_sums():
+    """Size-independent property at BASELINE config-2 scale: with alpha -> 0 every step adds +d to v_i[i] and -d to
+    v_i[j] (rankfm/_rankfm.pyx:309-310) and +/-g to w_i, so column sums of v_i and the sum of w_i are invariants of
+    ANY interleaving -- provided no update is lost.  Atomic adds keep them; a racy read-modify-write would not."""
+    from rankfm_amd import synthetic
+    from rankfm_amd.engine import DeviceSession
+    cfg = synthetic.CONFIGS["C2"]
+    U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=0)
+    w = synthetic.init_weights(U, I, F, seed=1492)
+    before = w["v_i"].astype(np.float64).sum(axis=0)
+    sess = DeviceSession(pairs, np.ones(N, np.float32), csr.offsets, csr.items, np.zeros((U, 1), np.float32),
+                         np.zeros((I, 1), np.float32), w, alpha=0.0, beta=0.0, max_samples=1, seed=1492)
+    rep = sess.run(epochs=1)
+    h = sess.weights_to_host()
+    after = h["v_i"].astype(np.float64).sum(axis=0)
+    moved = np.abs(h["v_i"] - w["v_i"]).astype(np.float64).sum(axis=0)      # total |delta| per column: O(1e4)
+    assert np.all(np.abs(after - before) <= 2e-5 * moved + 1e-3), (np.abs(after - before).max(), moved.min())
+    assert abs(float(h["w_i"].astype(np.float64).sum())) <= 2e-5 * float(np.abs(h["w_i"]).astype(np.float64).sum()) + 1e-3
+    assert np.isfinite(rep["log_likelihood"][0]) and rep["n_draws"][0] == N
+    # learning happened: mean log-likelihood per update well above the untrained log(0.5)
+    rep2 = sess.run(epochs=1, epoch_begin=1)
+    assert rep2["log_likelihood"][0] > rep["log_likelihood"][0]
+
+
+def test_fit_errors_cross_the_boundary_like_the_reference():
+    from rankfm_amd import EngineOptions
+    from rankfm_amd._rankfm import UserItemsCSR, _fit
+    g = load_golden("fit", "bpr_nofeat_const_f8")
+    w = {k: g["init_" + k].copy() for k in WEIGHTS}
+    args = [g["interactions"], g["sample_weight"], UserItemsCSR(g["csr_off"], g["csr_items"]), g["x_uf"], g["x_if"],
+            w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"], 0.01, 0.1, 0.1]
+    with pytest.raises(ValueError, match="learning_schedule"):
+        _fit(*args, "adaptive", 0.25, 1, 1, False)
+    with pytest.raises(ValueError, match="dtype"):
+        _fit(g["interactions"].astype(np.int64), *args[1:], "constant", 0.25, 1, 1, False)
+    w["v_u"][3, 2] = np.inf
+    with pytest.raises(AssertionError, match="not finite"):
+        _fit(*args, "constant", 0.25, 1, 1, False, engine=EngineOptions(seed=1))
+    # a user who has seen every item cannot be given a negative
+    I = g["init_v_i"].shape[0]
+    off = g["csr_off"].copy()
+    items = np.concatenate([np.arange(I, dtype=np.int32), g["csr_items"][off[1]:]])
+    off[1:] += I - off[1]
+    w = {k: g["init_" + k].copy() for k in WEIGHTS}
+    args[2] = UserItemsCSR(off, items)
+    args[5:11] = [w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"]]
+    with pytest.raises(ValueError, match="every item"):
+        _fit(*args, "constant", 0.25, 1, 1, False, engine=EngineOptions(seed=1))
+
+
+def test_verbose_prints_like_the_reference(capsys):
+    from rankfm_amd import REFERENCE_ENGINE
+    g = load_golden("fit", "bpr_nofeat_const_f8")
+    np.random.seed(S_SHUF)
+    _fit_from_golden(g, REFERENCE_ENGINE, verbose=True)
+    out = capsys.readouterr().out
+    assert out.count("training epoch:") == int(g["epochs"]) and "log likelihood:" in out
+    vals = [float(x.split(":")[1]) for x in out.splitlines() if x.startswith("log likelihood")]
+    np.testing.assert_allclose(vals, g["ll_printed"], atol=0.03)
