@@ -91,7 +91,13 @@ typedef struct rfm_fit_config {
     int32_t want_penalty;          /* 1: also return the L2 penalty per epoch (verbose printing) */
     int32_t n_workgroups;          /* 0 = auto (hogwild); ignored in serial mode */
     int32_t rows_per_launch;       /* 0 = one launch per epoch; >0 splits an epoch into several launches */
-    int32_t reserved[4];
+    float hogwild_damping;         /* M: a row touched by n in-flight updates at once is stepped with min(1, M/n) of the
+                                      learning rate (n = in-flight rows x the row's share of the data).  0 = default (128),
+                                      < 0 = off.  Ignored in serial mode. */
+    int32_t plan_is_cached;        /* 1: `workspace` still holds the per-item step scales an earlier call built for the SAME
+                                      interactions / geometry / damping (skips the popularity histogram) */
+    int32_t debug_update_mode;     /* experiments: 0 all atomics (default), 1 v_u plain stores, 2 everything plain stores */
+    int32_t debug_shape;           /* experiments: 1-based index into the kernel shape table, 0 = automatic */
 } rfm_fit_config;
 
 /* All pointers of one struct live in the same memory space: device memory for the *_device entry

@@ -32,7 +32,8 @@ class FitConfig(C.Structure):
         ("mode", C.c_int32), ("rng", C.c_int32), ("seed", C.c_uint32),
         ("check_finite", C.c_int32), ("want_penalty", C.c_int32),
         ("n_workgroups", C.c_int32), ("rows_per_launch", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("hogwild_damping", C.c_float), ("plan_is_cached", C.c_int32),
+        ("debug_update_mode", C.c_int32), ("debug_shape", C.c_int32),
     ]
 
 
@@ -89,6 +90,13 @@ def lib():
         raise EngineUnavailable(
             "%s not found: build it with `python -m rankfm_amd._build` (hipcc, gfx950). "
             "rankfm_amd has no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7 (same soname as /opt/rocm's).  Whichever
+    # is loaded first serves both, and PyTorch does not work on top of a foreign one -- so let PyTorch load its runtime
+    # before librankfm_hip.so binds to that soname.  (A host without PyTorch resolves it through the library's RUNPATH.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:

@@ -43,6 +43,7 @@ class EngineOptions:
     n_workgroups: int = 0
     rows_per_launch: int = 0
     check_finite: bool = True
+    damping: float = 0.0          # hogwild step damping M (include/rankfm_hip.h: hogwild_damping); 0 default, < 0 off
 
     def validated(self):
         if self.mode not in ("hogwild", "serial"):
@@ -189,7 +190,8 @@ def _fit(interactions, sample_weight, user_items, x_uf, x_if, w_i, w_if, v_u, v_
         mode=_hip.MODE_SERIAL if opt.mode == "serial" else _hip.MODE_HOGWILD,
         rng=_hip.RNG_MT19937 if opt.rng == "mt19937" else _hip.RNG_COUNTER, seed=seed & 0xFFFFFFFF,
         check_finite=int(opt.check_finite), want_penalty=int(bool(verbose) or report is not None),
-        n_workgroups=int(opt.n_workgroups), rows_per_launch=int(opt.rows_per_launch))
+        n_workgroups=int(opt.n_workgroups), rows_per_launch=int(opt.rows_per_launch),
+        hogwild_damping=float(opt.damping))
     buf = _hip.FitBuffers(
         interactions=_ptr(interactions), sample_weight=_ptr(sample_weight),
         csr_offsets=_ptr(csr.offsets), csr_items=_ptr(csr.items), x_uf=_ptr(x_uf), x_if=_ptr(x_if),

@@ -17,24 +17,27 @@
 
 namespace rfm {
 #define RFM_DECLARE_SHAPE(name) const sgd_launch_fn *sgd_table_##name();
-RFM_DECLARE_SHAPE(v4_g4_k1) RFM_DECLARE_SHAPE(v4_g8_k1) RFM_DECLARE_SHAPE(v4_g16_k1) RFM_DECLARE_SHAPE(v4_g32_k1)
-RFM_DECLARE_SHAPE(v4_g64_k1) RFM_DECLARE_SHAPE(v4_g64_k2)
-RFM_DECLARE_SHAPE(v1_g4_k1) RFM_DECLARE_SHAPE(v1_g16_k1) RFM_DECLARE_SHAPE(v1_g64_k1) RFM_DECLARE_SHAPE(v1_g64_k2)
-RFM_DECLARE_SHAPE(v1_g64_k4)
+RFM_DECLARE_SHAPE(g4_k1) RFM_DECLARE_SHAPE(g16_k1) RFM_DECLARE_SHAPE(g16_k2) RFM_DECLARE_SHAPE(g16_k3)
+RFM_DECLARE_SHAPE(g16_k4) RFM_DECLARE_SHAPE(g16_k6) RFM_DECLARE_SHAPE(g16_k8) RFM_DECLARE_SHAPE(g64_k3)
+RFM_DECLARE_SHAPE(g64_k4) RFM_DECLARE_SHAPE(g64_k8) RFM_DECLARE_SHAPE(g32_k2) RFM_DECLARE_SHAPE(g64_k1)
 
-struct ShapeEntry { int vec, group, kpl, max_f; const sgd_launch_fn *(*table)(); };
+// Row-group shapes: G lanes per interaction, lane s owns factor dwords s, s+G, s+2G, ... (KPL of them).  With
+// G = 16 every load / atomic instruction of a group covers one contiguous 64-byte segment of the row, which is
+// what the L2 atomic path wants: the first version of this kernel used 16-byte-per-lane chunks (4 dwords per
+// 64-byte segment per instruction) and ran its atomics 3.4x slower (profiles/r01_notes.md).
+struct ShapeEntry { int group, kpl, max_f; const sgd_launch_fn *(*table)(); };
 static const ShapeEntry kShapes[] = {
-    {4, 4, 1, 16, sgd_table_v4_g4_k1},   {4, 8, 1, 32, sgd_table_v4_g8_k1},    {4, 16, 1, 64, sgd_table_v4_g16_k1},
-    {4, 32, 1, 128, sgd_table_v4_g32_k1}, {4, 64, 1, 256, sgd_table_v4_g64_k1}, {4, 64, 2, 512, sgd_table_v4_g64_k2},
-    {1, 4, 1, 4, sgd_table_v1_g4_k1},     {1, 16, 1, 16, sgd_table_v1_g16_k1},  {1, 64, 1, 64, sgd_table_v1_g64_k1},
-    {1, 64, 2, 128, sgd_table_v1_g64_k2}, {1, 64, 4, 256, sgd_table_v1_g64_k4},
+    {4, 1, 4, sgd_table_g4_k1},     {16, 1, 16, sgd_table_g16_k1},  {16, 2, 32, sgd_table_g16_k2},
+    {16, 3, 48, sgd_table_g16_k3},  {16, 4, 64, sgd_table_g16_k4},  {16, 6, 96, sgd_table_g16_k6},
+    {16, 8, 128, sgd_table_g16_k8}, {64, 3, 192, sgd_table_g64_k3}, {64, 4, 256, sgd_table_g64_k4},
+    {64, 8, 512, sgd_table_g64_k8},
+    {32, 2, 0, sgd_table_g32_k2},   {64, 1, 0, sgd_table_g64_k1},   // experiments (max_f 0: never auto-picked)
 };
 
-// smallest row-group shape that holds F factors: 16-byte chunks when F is a multiple of 4
+// smallest row-group shape that holds F factors
 static const ShapeEntry *pick_shape(int F) {
-    const int vec = (F % 4 == 0) ? 4 : 1;
     for (const ShapeEntry &s : kShapes)
-        if (s.vec == vec && F <= s.max_f) return &s;
+        if (F <= s.max_f) return &s;
     return nullptr;
 }
 
@@ -113,9 +116,28 @@ __global__ void degree_check_kernel(const int64_t *__restrict__ off, int n_users
 }
 
 // ---------------------------------------------------------------------------------------------
+// Hogwild plan: per-item step scale from item popularity (see SgdArgs::pos_scale)
+// ---------------------------------------------------------------------------------------------
+__global__ void item_count_kernel(const int32_t *__restrict__ interactions, long long n, int *__restrict__ count) {
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x)
+        atomicAdd(count + interactions[2 * r + 1], 1);
+}
+
+// in place: int32 count -> float scale = min(1, cap / count)
+__global__ void item_scale_kernel(int *count, int n_items, float cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_items) {
+        const int c = count[i];
+        reinterpret_cast<float *>(count)[i] = c > 0 ? fminf(1.0f, cap / (float)c) : 1.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // workspace layout (device)
 // ---------------------------------------------------------------------------------------------
 struct Workspace {
+    float *pos_scale;             // [I]  persistent across calls (plan_is_cached)
+    size_t volatile_offset;       // everything from here on is zeroed at the start of every call
     double *ll;                   // [epochs]
     unsigned long long *draws;    // [epochs]
     double *sumsq;                // [epochs][6]
@@ -128,10 +150,12 @@ struct Workspace {
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static Workspace carve(void *base, int epochs, int max_samples) {
+static Workspace carve(void *base, int epochs, int max_samples, int n_items) {
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
+    w.pos_scale = (float *)(p + o);              o += align_up(sizeof(float) * (size_t)n_items);
+    w.volatile_offset = o;
     w.ll = (double *)(p + o);                    o += align_up(sizeof(double) * epochs);
     w.draws = (unsigned long long *)(p + o);     o += align_up(sizeof(unsigned long long) * epochs);
     w.sumsq = (double *)(p + o);                 o += align_up(sizeof(double) * 6 * epochs);
@@ -218,7 +242,7 @@ int rfm_fit_supported(const rfm_fit_config *cfg) { return validate(cfg); }
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
-    return carve(nullptr, cfg->epochs, cfg->max_samples).bytes;
+    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items).bytes;
 }
 
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
@@ -231,10 +255,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     if ((rc = device_ok()) != RFM_OK) return rc;
     const int E = cfg->epochs;
     const int64_t N = cfg->n_interactions;
-    const Workspace ws = carve(b->workspace, E, cfg->max_samples);
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items);
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
+    if (cfg->debug_shape > 0 && cfg->debug_shape <= (int)(sizeof(kShapes) / sizeof(kShapes[0]))) shape = &kShapes[cfg->debug_shape - 1];
     const bool serial = cfg->mode == RFM_MODE_SERIAL;
     const bool feat = cfg->has_user_features || cfg->has_item_features;
     const sgd_launch_fn launch = shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
@@ -244,7 +269,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     std::vector<float> mult((size_t)cfg->max_samples + 1, 0.0f);
     for (int s = 1; s <= cfg->max_samples; ++s)
         mult[s] = (float)(log((double)((cfg->n_items - 1) / s)) / log((double)cfg->n_items));
-    RFM_HIP(hipMemsetAsync(b->workspace, 0, ws.bytes, stream));
+    RFM_HIP(hipMemsetAsync((char *)b->workspace + ws.volatile_offset, 0, ws.bytes - ws.volatile_offset, stream));
     RFM_HIP(hipMemcpyAsync(ws.multiplier, mult.data(), mult.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     std::vector<uint32_t> mt(625);
     if (cfg->rng == RFM_RNG_MT19937) {
@@ -264,11 +289,31 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         if (cfg->rows_per_launch > 0 && cfg->rows_per_launch < rows_per_launch) rows_per_launch = cfg->rows_per_launch;
         const int64_t rows_per_block = (int64_t)rows_per_wave * 4;
         const int64_t need = (rows_per_launch + rows_per_block - 1) / rows_per_block;
-        const int64_t cap = cfg->n_workgroups > 0 ? cfg->n_workgroups : (int64_t)(g_sm_count > 0 ? g_sm_count : 256) * 8;
+        // Default concurrency: 4 workgroups of 4 wavefronts per CU (1024 workgroups, 16 k rows in flight on MI355X).
+        // Measured on BASELINE config 2 the update rate saturates there (profiles/r01_notes.md); more wavefronts only
+        // add staleness.  All workgroups are resident, so the wavefronts sweep the shuffled positions together and the
+        // realised order stays close to the sequential one.  Never keep more than 1/128 of an epoch in flight: every
+        // in-flight update reads weights that are stale by up to that many steps, and Hogwild only tracks sequential
+        // SGD while that window is a small fraction of the data (DESIGN.md "staleness").
+        int64_t cap = (int64_t)(g_sm_count > 0 ? g_sm_count : 256) * 4;
+        const int64_t window = (N / 128 + rows_per_block - 1) / rows_per_block;
+        if (window < cap) cap = window;
+        if (cfg->n_workgroups > 0) cap = cfg->n_workgroups;
         grid = (int)(need < cap ? need : cap);
         if (grid < 1) grid = 1;
     }
     const int launches = (int)((N + rows_per_launch - 1) / rows_per_launch);
+
+    // ---- Hogwild damping plan: n(row) = in-flight rows x share of the data; scale = min(1, M / n) = min(1, cap / count)
+    const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
+    const bool damp = !serial && damp_m > 0.0f && N > 0;
+    const long long in_flight = (long long)grid * 4 * rows_per_wave;
+    const float damp_cap = damp ? damp_m * (float)N / (float)in_flight : 0.0f;
+    if (damp && !cfg->plan_is_cached) {
+        RFM_HIP(hipMemsetAsync(ws.pos_scale, 0, sizeof(float) * (size_t)cfg->n_items, stream));
+        item_count_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, (long long)N, (int *)ws.pos_scale);
+        item_scale_kernel<<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>((int *)ws.pos_scale, cfg->n_items, damp_cap);
+    }
 
     std::vector<hipEvent_t> ev((size_t)2 * E, nullptr);
     const bool timing = rep && rep->sgd_kernel_ms;
@@ -295,6 +340,13 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
                     : (float)((double)cfg->learning_rate / pow((double)(epoch + 1), (double)cfg->learning_exponent));
         a.reg_a = 2.0f * cfg->alpha;      // :171
         a.reg_b = 2.0f * cfg->beta;       // :172
+        a.update_mode = cfg->debug_update_mode;
+        a.pos_scale = damp ? ws.pos_scale : nullptr;
+        a.user_cap = damp ? damp_cap : INFINITY;
+        // the dense feature tables are touched by EVERY in-flight row and shrink by 2*beta*eta per touch: keep the summed
+        // stale shrink of one in-flight window below 1/2 as well
+        a.feat_scale = damp ? fminf(1.0f, fminf(damp_m / (float)in_flight,
+                                                0.5f / ((float)in_flight * a.eta * fmaxf(a.reg_b, 1e-6f)))) : 1.0f;
 
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e], stream));
         for (int64_t p0 = 0; p0 < N; p0 += rows_per_launch) {

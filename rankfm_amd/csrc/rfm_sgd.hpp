@@ -49,6 +49,13 @@ struct SgdArgs {
     int32_t rng;                                // RFM_RNG_*
     uint32_t epoch_key, perm_bits;
     float eta, reg_a, reg_b;                    // learning rate of the epoch, 2*alpha, 2*beta
+    // Hogwild step damping (DESIGN.md "staleness"): a row that n in-flight updates touch at once receives n steps computed
+    // from the same stale value; above ~M of them the combined step overshoots.  The step on such a row is scaled by
+    // min(1, M / n), with n = in-flight rows x the row's share of the data.  All 1 / null in serial mode.
+    const float *__restrict__ pos_scale;        // [I] scale for the positive item's row (by item popularity), or nullptr
+    float user_cap;                             // a user of degree d gets min(1, user_cap / d)
+    float feat_scale;                           // scale for the dense feature tables (every row touches them)
+    int32_t update_mode;                        // hogwild experiments: 0 all atomics, 1 v_u plain RMW, 2 everything plain RMW
 };
 
 constexpr float kMargin = 1.0f;                 // rankfm/_rankfm.pyx:149
@@ -87,8 +94,8 @@ __device__ __forceinline__ void store_chunk(float *p, const float (&r)[VEC]) {
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
 
 template <bool SERIAL, int VEC>
-__device__ __forceinline__ void apply_chunk(float *p, const float (&oldv)[VEC], const float (&delta)[VEC]) {
-    if constexpr (SERIAL) {
+__device__ __forceinline__ void apply_chunk(float *p, const float (&oldv)[VEC], const float (&delta)[VEC], bool plain = false) {
+    if (SERIAL || plain) {
         float n[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) n[e] = oldv[e] + delta[e];
@@ -283,10 +290,16 @@ struct RowStep {
         const float d_outer = 1.0f / (__expf(pu) + 1.0f);                 // :276
         const float g = sw * multiplier;
         const float eta = a.eta, reg_a = a.reg_a, reg_b = a.reg_b;
+        float eta_u = eta, eta_i = eta, eta_f = eta;
+        if constexpr (!SERIAL) {
+            eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
+            if (a.pos_scale) eta_i = eta * a.pos_scale[i];
+            eta_f = eta * a.feat_scale;
+        }
 
         // item biases (:279-280) -- one lane per group
         if (sub == 0) {
-            const float dwi = eta * (g * (d_outer * 1.0f) - reg_a * wi);
+            const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
             if constexpr (SERIAL) { a.w_i[i] = wi + dwi; a.w_i[j] = wj + dwj; }
             else { atomic_add_f32(a.w_i + i, dwi); atomic_add_f32(a.w_i + j, dwj); }
@@ -298,7 +311,7 @@ struct RowStep {
                 const float *xi = a.x_if + (size_t)i * a.n_if, *xj = a.x_if + (size_t)j * a.n_if;
                 for (int q = sub; q < a.n_if; q += G) {
                     const float w = a.w_if[q];
-                    const float d = eta * (g * (d_outer * (xi[q] - xj[q])) - reg_b * w);
+                    const float d = eta_f * (g * (d_outer * (xi[q] - xj[q])) - reg_b * w);
                     if constexpr (SERIAL) a.w_if[q] = w + d; else atomic_add_f32(a.w_if + q, d);
                 }
             }
@@ -314,17 +327,17 @@ struct RowStep {
                 float g_u = vi[k][e] - vj[k][e];                          // :292
                 float g_i = vu[k][e];                                     // :293-294 (d_v_j = -d_v_i)
                 if constexpr (FEAT) { g_i += A[k][e]; g_u += Bi[k][e] - Bj[k][e]; }   // :297-305
-                d_u[e] = eta * (g * (d_outer * g_u) - reg_a * vu[k][e]);  // :308
-                d_i[e] = eta * (g * (d_outer * g_i) - reg_a * vi[k][e]);  // :309
+                d_u[e] = eta_u * (g * (d_outer * g_u) - reg_a * vu[k][e]);  // :308
+                d_i[e] = eta_i * (g * (d_outer * g_i) - reg_a * vi[k][e]);  // :309
                 d_j[e] = eta * (g * (d_outer * -g_i) - reg_a * vj[k][e]); // :310
                 nvu[k][e] = vu[k][e] + d_u[e];
                 dij[k][e] = (vi[k][e] + d_i[e]) - (vj[k][e] + d_j[e]);
             }
             if (chunk_ok(k)) {
                 const int f0 = chunk_f(k);
-                apply_chunk<SERIAL, VEC>(a.v_u + (size_t)u * F + f0, vu[k], d_u);
-                apply_chunk<SERIAL, VEC>(a.v_i + (size_t)i * F + f0, vi[k], d_i);
-                apply_chunk<SERIAL, VEC>(a.v_i + (size_t)j * F + f0, vj[k], d_j);
+                apply_chunk<SERIAL, VEC>(a.v_u + (size_t)u * F + f0, vu[k], d_u, a.update_mode >= 1);
+                apply_chunk<SERIAL, VEC>(a.v_i + (size_t)i * F + f0, vi[k], d_i, a.update_mode >= 2);
+                apply_chunk<SERIAL, VEC>(a.v_i + (size_t)j * F + f0, vj[k], d_j, a.update_mode >= 2);
             }
         }
 
@@ -342,7 +355,7 @@ struct RowStep {
                         float t[VEC], d[VEC];
                         load_chunk<VEC>(trow + chunk_f(k), t);
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) d[e] = eta * (g * (d_outer * (xp * dij[k][e])) - reg_b * t[e]);
+                        for (int e = 0; e < VEC; ++e) d[e] = eta_f * (g * (d_outer * (xp * dij[k][e])) - reg_b * t[e]);
                         apply_chunk<SERIAL, VEC>(trow + chunk_f(k), t, d);
                     }
                 }
@@ -360,7 +373,7 @@ struct RowStep {
                         float t[VEC], d[VEC];
                         load_chunk<VEC>(trow + chunk_f(k), t);
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) d[e] = eta * (g * (d_outer * (dx * nvu[k][e])) - reg_b * t[e]);
+                        for (int e = 0; e < VEC; ++e) d[e] = eta_f * (g * (d_outer * (dx * nvu[k][e])) - reg_b * t[e]);
                         apply_chunk<SERIAL, VEC>(trow + chunk_f(k), t, d);
                     }
                 }

@@ -6,11 +6,15 @@ The reference is single-process (no counterpart to cite); the design follows SUR
     interactions, CSR slice, `v_u` rows and `x_uf` rows exclusively -- no traffic for them, ever;
   * the item-side / shared tables (`v_i, w_i, v_if, w_if, v_uf`) are replicated.  They live in ONE flat fp32
     buffer per rank (the weight tensors are views into it), so the exchange step is a single bucket:
-        delta = flat - flat_at_epoch_start;  all_reduce(delta, SUM);  flat = flat_at_epoch_start + delta
-    i.e. every rank ends the epoch with all ranks' updates applied (sum of deltas; `average=True` gives the
-    conservative mean).  One all-reduce per epoch (or per `syncs_per_epoch` slice of it): 13 MB at BASELINE
-    config 2, 52 MB at config 4, 516 MB at config 5 -- a few ms on 7 x 153 GB/s xGMI links against epochs of
-    tens to hundreds of ms, so one large collective per epoch is the right granularity for point-to-point xGMI.
+        delta = flat - flat_at_epoch_start;  all_reduce(delta, SUM);  flat = flat_at_epoch_start + scale * delta
+    One all-reduce per epoch: 13 MB at BASELINE config 2, 52 MB at config 4, 516 MB at config 5 -- a few ms on
+    7 x 153 GB/s xGMI links against epochs of tens to hundreds of ms, so one large collective per epoch is the right
+    granularity for point-to-point xGMI.
+  * `scale` is the same stale-step damping the single-GPU engine applies to hot rows (DESIGN.md "staleness"): a row
+    that received n updates across all ranks during the window gets min(1, M / n) of the summed delta, never less
+    than the plain average 1/world.  Rarely-touched rows therefore end the epoch with every rank's updates applied
+    (sum of deltas), rows every rank hammered end at the ranks' average (summing K near-converged local moves
+    would overshoot K-fold), and the dense feature tables are always averaged.
 
 Everything here works on CPU tensors with the gloo backend as well, which is how the N > 1 logic is tested
 without GPUs (tests/test_distributed_cpu.py).
@@ -63,6 +67,21 @@ class SharedTables:
             v.copy_(torch.as_tensor(np.asarray(tables[k]), dtype=torch.float32))
             self.views[k] = v
         self.start = self.flat.clone()
+        self._starts, self._sizes, self._shapes = starts, sizes, shapes
+        self.merge_scale = None          # per-element damping of the summed deltas (None = plain sum)
+
+    def set_merge_damping(self, item_counts_all_ranks, world_size, damping=128.0):
+        """per-element scale of the summed deltas: min(1, M / n_i) clipped below at 1/world_size for item i that all
+        ranks together update n_i times per exchange window; 1/world_size (average) for the dense feature tables"""
+        n = torch.as_tensor(np.asarray(item_counts_all_ranks, dtype=np.float64), dtype=torch.float32, device=self.flat.device)
+        s_item = torch.clamp(float(damping) / torch.clamp(n, min=1.0), min=1.0 / world_size, max=1.0)
+        scale = torch.full_like(self.flat, 1.0 / world_size)
+        F = self._shapes["v_i"][1]
+        a = self._starts["v_i"]
+        scale[a:a + self._sizes["v_i"]] = s_item.repeat_interleave(F)
+        a = self._starts["w_i"]
+        scale[a:a + self._sizes["w_i"]] = s_item
+        self.merge_scale = scale if world_size > 1 else None
 
     def begin_epoch(self):
         self.start.copy_(self.flat)
@@ -75,6 +94,8 @@ class SharedTables:
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if average:
             self.flat.div_(dist.get_world_size(group))
+        elif self.merge_scale is not None:
+            self.flat.mul_(self.merge_scale)
         self.flat.add_(self.start)
 
     @property
@@ -107,11 +128,17 @@ class ShardedTrainer:
         return out
 
 
-def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, **session_kw):
+def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=128.0,
+                        **session_kw):
     """wire a rank's shard to the HIP engine: weights are views into the flat bucket, so the engine's in-place
     atomics and the all-reduce act on the same memory"""
     from .engine import DeviceSession
     shared = SharedTables(shared_tables, device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        counts = torch.bincount(torch.as_tensor(np.asarray(shard["interactions"])[:, 1].astype(np.int64)),
+                                minlength=shared.views["w_i"].shape[0]).to(device=device, dtype=torch.float32)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        shared.set_merge_damping(counts.cpu().numpy(), dist.get_world_size(group), merge_damping)
     weights = dict(shared.views)
     weights["v_u"] = torch.as_tensor(shard["v_u"]).to(device)
     sess = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"],

@@ -28,7 +28,7 @@ def _relevance(model, test_interactions, k, filter_previous):
                          'item_id': recs.values.reshape(-1)})
     held = pd.DataFrame({'row': pos.loc[test['user_id'].values].values, 'item_id': test['item_id'].values, 'hit': True})
     merged = long.merge(held, on=['row', 'item_id'], how='left')
-    hits = merged['hit'].fillna(False).values.astype(bool).reshape(len(users), recs.shape[1])
+    hits = merged['hit'].notna().values.reshape(len(users), recs.shape[1])
     n_test = held.groupby('row')['item_id'].nunique().reindex(np.arange(len(users)), fill_value=0).values
     return hits, n_test, recs
 

@@ -1,0 +1,122 @@
+"""The C-ABI library: loads on a CPU-only box, exports every symbol include/rankfm_hip.h declares, its structs have the
+layout the ctypes binding assumes, validation works without a device, and compute entry points refuse loudly without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from rankfm_amd import _build, _hip
+
+HEADER = os.path.join(ROOT, "include", "rankfm_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _build.build()
+    return _hip.lib()
+
+
+def test_exports_every_declared_symbol(lib):
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    declared = set(re.findall(r"\b(rfm_[a-z_0-9]+)\s*\(", text))
+    assert declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
+    nm = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (rfm_[a-z_0-9]+)", nm))
+    assert declared <= exported, declared - exported
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.rfm_abi_version() == _hip.ABI_VERSION
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """compile the header with gcc and compare sizeof/offsetof with the ctypes mirror"""
+    structs = {"rfm_fit_config": _hip.FitConfig, "rfm_fit_buffers": _hip.FitBuffers, "rfm_fit_report": _hip.FitReport,
+               "rfm_model_view": _hip.ModelView}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rankfm_hip.h"', 'int main(void){']
+    for cname, ct in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in ct._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for f, _ in ct._fields_:
+            assert int(got["%s.%s" % (cname, f)]) == getattr(ct, f).offset, (cname, f)
+
+
+def _cfg(**kw):
+    base = dict(n_interactions=100, n_users=10, n_items=20, n_user_features=1, n_item_features=1, n_factors=8,
+                alpha=0.01, beta=0.1, learning_rate=0.1, learning_schedule=0, learning_exponent=0.25, max_samples=1,
+                epochs=1, mode=_hip.MODE_HOGWILD, rng=_hip.RNG_COUNTER, seed=1)
+    base.update(kw)
+    return _hip.FitConfig(**base)
+
+
+def test_validation_needs_no_device(lib):
+    assert lib.rfm_fit_supported(C.byref(_cfg())) == _hip.OK
+    assert lib.rfm_fit_workspace_bytes(C.byref(_cfg())) > 0
+    assert lib.rfm_fit_supported(C.byref(_cfg(learning_schedule=7))) == _hip.ERR_UNKNOWN_SCHEDULE
+    assert lib.rfm_fit_supported(C.byref(_cfg(max_samples=0))) == _hip.ERR_BAD_ARG
+    assert lib.rfm_fit_supported(C.byref(_cfg(n_items=1))) == _hip.ERR_BAD_ARG
+    assert lib.rfm_fit_supported(C.byref(_cfg(rng=_hip.RNG_MT19937))) == _hip.ERR_BAD_ARG          # MT needs serial mode
+    assert lib.rfm_fit_supported(C.byref(_cfg(rng=_hip.RNG_MT19937, mode=_hip.MODE_SERIAL))) == _hip.OK
+    assert lib.rfm_fit_supported(C.byref(_cfg(n_factors=513))) == _hip.ERR_UNSUPPORTED
+    for F in (1, 2, 3, 10, 16, 20, 50, 64, 100, 128, 200, 256, 512):
+        assert lib.rfm_fit_supported(C.byref(_cfg(n_factors=F))) == _hip.OK, F
+    assert lib.rfm_fit_workspace_bytes(C.byref(_cfg(epochs=0))) == 0
+    assert lib.rfm_fit_supported(None) == _hip.ERR_BAD_ARG
+
+
+def test_status_strings_carry_the_reference_messages(lib):
+    names = ["[w_i]", "[w_if]", "[v_u]", "[v_i]", "[v_uf]", "[v_if]"]               # order of rankfm/_rankfm.pyx:98-103
+    for k, n in enumerate(names):
+        msg = _hip.status_string(_hip.ERR_NONFINITE + k)
+        assert n in msg and "are not finite" in msg
+    assert "learning_schedule" in _hip.status_string(_hip.ERR_UNKNOWN_SCHEDULE)
+    with pytest.raises(AssertionError):
+        _hip.raise_for_status(_hip.ERR_NONFINITE + 2)
+    with pytest.raises(ValueError):
+        _hip.raise_for_status(_hip.ERR_UNKNOWN_SCHEDULE)
+    with pytest.raises(_hip.EngineUnavailable):
+        _hip.raise_for_status(_hip.ERR_NO_DEVICE)
+
+
+def test_compute_entry_points_refuse_without_a_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.rfm_device_count() == 0
+    from rankfm_amd._rankfm import UserItemsCSR, _fit, _predict, _recommend
+    X = np.array([[0, 1], [1, 2], [2, 0]], dtype=np.int32)
+    csr = UserItemsCSR.from_pairs(X[:, 0], X[:, 1], 3)
+    w = dict(w_i=np.zeros(3, np.float32), w_if=np.zeros(1, np.float32), v_u=np.zeros((3, 4), np.float32),
+             v_i=np.zeros((3, 4), np.float32), v_uf=np.zeros((1, 4), np.float32), v_if=np.zeros((1, 4), np.float32))
+    z_u, z_i = np.zeros((3, 1), np.float32), np.zeros((3, 1), np.float32)
+    with pytest.raises(_hip.EngineUnavailable):
+        _fit(X, np.ones(3, np.float32), csr, z_u, z_i, w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"],
+             0.01, 0.1, 0.1, "constant", 0.25, 1, 1, False)
+    with pytest.raises(_hip.EngineUnavailable):
+        _predict(np.zeros((2, 2), np.float32), z_u, z_i, w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"])
+    with pytest.raises(_hip.EngineUnavailable):
+        _recommend(np.zeros(2, np.float32), csr, 2, False, z_u, z_i, w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"])
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is checker infrastructure: nothing under rankfm_amd/ may import, load or link it"""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "rankfm_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".hip", ".hpp", ".inc", ".h")):
+            text = open(path).read()
+            assert "librfm_oracle" not in text and "rfm_oracle" not in text.replace("oracle/rfm_oracle.c", ""), path
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), path

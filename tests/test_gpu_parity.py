@@ -125,19 +125,48 @@ def test_hogwild_features_statistical_parity(oracle):
     _assert_statistical_parity(g, rep, o, out, names=("v_u", "v_i", "w_i", "v_uf", "v_if", "w_if"), norm_tol=0.05, corr=0.95)
 
 
-def test_hogwild_conserves_item_factor_sums():
+@pytest.fixture(scope="module")
+def c2_problem():
+    """BASELINE.json config 2 at full size (seeded)"""
+    from rankfm_amd import synthetic
+    cfg = synthetic.CONFIGS["C2"]
+    U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=0)
+    return U, I, N, F, pairs, csr
+
+
+def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
+    """BASELINE config 2 at FULL size, default (full-chip) concurrency: two epochs of Hogwild on the GPU against two
+    epochs of the sequential CPU oracle on the same counter-based draws and visiting order.  Norms and per-epoch
+    log-likelihood within 2 %, element-wise correlation of the learned factors > 0.98."""
+    from rankfm_amd import synthetic
+    from rankfm_amd.engine import DeviceSession
+    U, I, N, F, pairs, csr = c2_problem
+    w = synthetic.init_weights(U, I, F, seed=1492)
+    sw = np.ones(N, np.float32)
+    x_uf, x_if = np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32)
+    sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=1, seed=1492)
+    rep = sess.run(epochs=2)
+    g = sess.weights_to_host()
+    o = {k: v.copy() for k, v in w.items()}
+    out = oracle.fit(pairs, sw, csr.offsets, csr.items, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"],
+                     0.01, 0.1, 0.1, "constant", 0.25, 1, 2, perms=None, rng_mode=oracle.RNG_COUNTER, seed=1492,
+                     membership="binary")
+    _assert_statistical_parity(g, rep, o, out)
+
+
+def test_hogwild_conserves_item_factor_sums(c2_problem):
     """Size-independent property at BASELINE config-2 scale: with alpha -> 0 every step adds +d to v_i[i] and -d to
     v_i[j] (rankfm/_rankfm.pyx:309-310) and +/-g to w_i, so column sums of v_i and the sum of w_i are invariants of
     ANY interleaving -- provided no update is lost.  Atomic adds keep them; a racy read-modify-write would not."""
     from rankfm_amd import synthetic
     from rankfm_amd.engine import DeviceSession
-    cfg = synthetic.CONFIGS["C2"]
-    U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
-    pairs, csr = synthetic.make_interactions(U, I, N, seed=0)
+    U, I, N, F, pairs, csr = c2_problem
     w = synthetic.init_weights(U, I, F, seed=1492)
     before = w["v_i"].astype(np.float64).sum(axis=0)
     sess = DeviceSession(pairs, np.ones(N, np.float32), csr.offsets, csr.items, np.zeros((U, 1), np.float32),
-                         np.zeros((I, 1), np.float32), w, alpha=0.0, beta=0.0, max_samples=1, seed=1492)
+                         np.zeros((I, 1), np.float32), w, alpha=0.0, beta=0.0, max_samples=1, seed=1492,
+                         hogwild_damping=-1.0)      # damping rescales the positive item's step only: switch it off here
     rep = sess.run(epochs=1)
     h = sess.weights_to_host()
     after = h["v_i"].astype(np.float64).sum(axis=0)

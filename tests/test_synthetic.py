@@ -1,0 +1,47 @@
+"""workload generator + counter RNG spec properties (CPU)"""
+import numpy as np
+import pytest
+
+from rankfm_amd import synthetic
+
+
+@pytest.mark.parametrize("zipf", [0.0, 1.0])
+def test_interactions_are_unique_exact_and_unsaturated(zipf):
+    U, I, N = 500, 200, 20000
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=3, zipf_s=zipf)
+    assert pairs.shape == (N, 2) and pairs.dtype == np.int32
+    assert len(np.unique(pairs[:, 0].astype(np.int64) * I + pairs[:, 1])) == N
+    assert pairs[:, 0].min() >= 0 and pairs[:, 0].max() < U and pairs[:, 1].max() < I
+    deg = np.diff(csr.offsets)
+    assert deg.sum() == N and deg.max() < I
+    for u in (0, 17, U - 1):
+        mine = np.sort(pairs[pairs[:, 0] == u, 1])
+        assert np.array_equal(csr[u], mine)
+    again, _ = synthetic.make_interactions(U, I, N, seed=3, zipf_s=zipf)
+    assert np.array_equal(pairs, again)
+    if zipf:
+        cnt = np.sort(np.bincount(pairs[:, 1], minlength=I))[::-1]
+        assert cnt[0] > 5 * np.median(cnt)          # a popularity head exists
+
+
+def test_too_dense_is_rejected():
+    with pytest.raises(ValueError):
+        synthetic.make_interactions(10, 5, 45)
+
+
+def test_init_weights_follow_reference_law():
+    w = synthetic.init_weights(1000, 800, 16, n_user_features=4, n_item_features=0, sigma=0.1, alpha=0.01, beta=0.1, seed=1)
+    assert w["v_u"].shape == (1000, 16) and w["v_u"].dtype == np.float32
+    assert abs(w["v_u"].std() - 0.1) < 0.005 and abs(w["v_uf"].std() - 0.01) < 0.004      # (alpha/beta) * sigma
+    assert not w["w_i"].any() and not w["w_if"].any() and not w["v_if"].any() and w["v_if"].shape == (1, 16)
+
+
+def test_configs_match_baseline_json():
+    import json
+    import os
+    from conftest import ROOT
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert len(base["configs"]) == len(synthetic.CONFIGS) == 5
+    c2 = synthetic.CONFIGS["C2"]
+    assert (c2["n_users"], c2["n_items"], c2["n_interactions"], c2["factors"], c2["loss"]) == (100_000, 50_000, 5_000_000, 64, "bpr")
+    assert "100k users" in base["configs"][1] and "5M interactions" in base["configs"][1] and "factors=64" in base["configs"][1]
