@@ -94,10 +94,14 @@ typedef struct rfm_fit_config {
     float hogwild_damping;         /* M: a row touched by n in-flight updates at once is stepped with min(1, M/n) of the
                                       learning rate (n = in-flight rows x the row's share of the data).  0 = default (128),
                                       < 0 = off.  Ignored in serial mode. */
-    int32_t plan_is_cached;        /* 1: `workspace` still holds the per-item step scales an earlier call built for the SAME
-                                      interactions / geometry / damping (skips the popularity histogram) */
     int32_t debug_update_mode;     /* experiments: 0 all atomics (default), 1 v_u plain stores, 2 everything plain stores */
     int32_t debug_shape;           /* experiments: 1-based index into the kernel shape table, 0 = automatic */
+    int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
+                                      bit 1: factor-row loads bypass the per-CU L1 */
+    int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
+                                      scales) into the head of `workspace`; > 0: the value rfm_fit_report.plan_token returned
+                                      by an earlier call on the SAME workspace, interactions, geometry and damping -- the
+                                      plan is reused and the planning pass is skipped */
 } rfm_fit_config;
 
 /* All pointers of one struct live in the same memory space: device memory for the *_device entry
@@ -130,6 +134,7 @@ typedef struct rfm_fit_report {
     int32_t nonfinite_array;       /* -1, or 0..5 when the status is RFM_ERR_NONFINITE + k */
     int32_t launches_per_epoch;
     int32_t waves_per_launch;
+    int64_t plan_token;            /* pass back as rfm_fit_config.plan_token to reuse the plan held in `workspace` */
 } rfm_fit_report;
 
 int rfm_abi_version(void);

@@ -32,8 +32,9 @@ class FitConfig(C.Structure):
         ("mode", C.c_int32), ("rng", C.c_int32), ("seed", C.c_uint32),
         ("check_finite", C.c_int32), ("want_penalty", C.c_int32),
         ("n_workgroups", C.c_int32), ("rows_per_launch", C.c_int32),
-        ("hogwild_damping", C.c_float), ("plan_is_cached", C.c_int32),
-        ("debug_update_mode", C.c_int32), ("debug_shape", C.c_int32),
+        ("hogwild_damping", C.c_float),
+        ("debug_update_mode", C.c_int32), ("debug_shape", C.c_int32), ("debug_flags", C.c_int32),
+        ("plan_token", C.c_int64),
     ]
 
 
@@ -54,6 +55,7 @@ class FitReport(C.Structure):
         ("sgd_kernel_ms", C.POINTER(C.c_float)), ("n_draws", C.POINTER(C.c_int64)),
         ("epochs_done", C.c_int32), ("nonfinite_array", C.c_int32),
         ("launches_per_epoch", C.c_int32), ("waves_per_launch", C.c_int32),
+        ("plan_token", C.c_int64),
     ]
 
 

@@ -19,7 +19,7 @@ namespace rfm {
 #define RFM_DECLARE_SHAPE(name) const sgd_launch_fn *sgd_table_##name();
 RFM_DECLARE_SHAPE(g4_k1) RFM_DECLARE_SHAPE(g16_k1) RFM_DECLARE_SHAPE(g16_k2) RFM_DECLARE_SHAPE(g16_k3)
 RFM_DECLARE_SHAPE(g16_k4) RFM_DECLARE_SHAPE(g16_k6) RFM_DECLARE_SHAPE(g16_k8) RFM_DECLARE_SHAPE(g64_k3)
-RFM_DECLARE_SHAPE(g64_k4) RFM_DECLARE_SHAPE(g64_k8) RFM_DECLARE_SHAPE(g32_k2) RFM_DECLARE_SHAPE(g64_k1)
+RFM_DECLARE_SHAPE(g64_k4) RFM_DECLARE_SHAPE(g64_k8)
 
 // Row-group shapes: G lanes per interaction, lane s owns factor dwords s, s+G, s+2G, ... (KPL of them).  With
 // G = 16 every load / atomic instruction of a group covers one contiguous 64-byte segment of the row, which is
@@ -31,7 +31,6 @@ static const ShapeEntry kShapes[] = {
     {16, 3, 48, sgd_table_g16_k3},  {16, 4, 64, sgd_table_g16_k4},  {16, 6, 96, sgd_table_g16_k6},
     {16, 8, 128, sgd_table_g16_k8}, {64, 3, 192, sgd_table_g64_k3}, {64, 4, 256, sgd_table_g64_k4},
     {64, 8, 512, sgd_table_g64_k8},
-    {32, 2, 0, sgd_table_g32_k2},   {64, 1, 0, sgd_table_g64_k1},   // experiments (max_f 0: never auto-picked)
 };
 
 // smallest row-group shape that holds F factors
@@ -132,11 +131,34 @@ __global__ void item_scale_kernel(int *count, int n_items, float cap) {
     }
 }
 
+// sample weights re-ordered to CSR positions: row r = (u, i) takes the first free slot among the positions of user u that
+// hold item i (duplicates of a pair occupy consecutive positions).  `sw_csr` is pre-filled with the sentinel 0xFFFFFFFF.
+__global__ void sw_to_csr_kernel(const int32_t *__restrict__ interactions, const float *__restrict__ sw, long long n,
+                                 const int64_t *__restrict__ off, const int32_t *__restrict__ items, unsigned int *sw_csr,
+                                 unsigned int *error_flags) {
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        const int32_t u = interactions[2 * r], i = interactions[2 * r + 1];
+        int64_t lo = off[u];
+        const int64_t end = off[u + 1];
+        int64_t hi = end;
+        while (lo < hi) {                                   // lower bound of i in the user's sorted list
+            const int64_t md = lo + ((hi - lo) >> 1);
+            if (items[md] < i) lo = md + 1; else hi = md;
+        }
+        bool placed = false;
+        for (int64_t slot = lo; slot < end && items[slot] == i; ++slot)
+            if (atomicCAS(sw_csr + slot, 0xFFFFFFFFu, __float_as_uint(sw[r])) == 0xFFFFFFFFu) { placed = true; break; }
+        if (!placed) atomicOr(error_flags, 4u);             // the CSR lists do not describe these interactions
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // workspace layout (device)
 // ---------------------------------------------------------------------------------------------
 struct Workspace {
-    float *pos_scale;             // [I]  persistent across calls (plan_is_cached)
+    float *pos_scale;             // [I]     persistent across calls (plan_is_cached)
+    float *sw_csr;                // [N]     persistent
+    int4 *seg_desc;               // [<= U + N / kSegmentRows]  persistent
     size_t volatile_offset;       // everything from here on is zeroed at the start of every call
     double *ll;                   // [epochs]
     unsigned long long *draws;    // [epochs]
@@ -150,11 +172,15 @@ struct Workspace {
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static Workspace carve(void *base, int epochs, int max_samples, int n_items) {
+static size_t max_segments(int64_t n_rows, int n_users) { return (size_t)n_users + (size_t)(n_rows / kSegmentRows) + 1; }
+
+static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows) {
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
     w.pos_scale = (float *)(p + o);              o += align_up(sizeof(float) * (size_t)n_items);
+    w.sw_csr = (float *)(p + o);                 o += align_up(sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1));
+    w.seg_desc = (int4 *)(p + o);                o += align_up(sizeof(int4) * max_segments(n_rows, n_users));
     w.volatile_offset = o;
     w.ll = (double *)(p + o);                    o += align_up(sizeof(double) * epochs);
     w.draws = (unsigned long long *)(p + o);     o += align_up(sizeof(unsigned long long) * epochs);
@@ -242,7 +268,7 @@ int rfm_fit_supported(const rfm_fit_config *cfg) { return validate(cfg); }
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
-    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items).bytes;
+    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions).bytes;
 }
 
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
@@ -255,14 +281,18 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     if ((rc = device_ok()) != RFM_OK) return rc;
     const int E = cfg->epochs;
     const int64_t N = cfg->n_interactions;
-    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items);
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N);
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
     if (cfg->debug_shape > 0 && cfg->debug_shape <= (int)(sizeof(kShapes) / sizeof(kShapes[0]))) shape = &kShapes[cfg->debug_shape - 1];
     const bool serial = cfg->mode == RFM_MODE_SERIAL;
     const bool feat = cfg->has_user_features || cfg->has_item_features;
-    const sgd_launch_fn launch = shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
+    // production Hogwild walks user segments of the CSR lists; that needs the lists to BE the interactions.  When they are
+    // not (fit_partial keeps earlier items in the lists, rankfm/rankfm.py:170-172) or the caller dictates the order, the
+    // rows kernel runs instead.  kRowsPlan marks such a plan in plan_token.
+    constexpr int64_t kRowsPlan = (int64_t)1 << 62;
+    bool use_segments = !serial && !b->perms && N > 0 && cfg->plan_token != kRowsPlan;
 
     // ---- host-side constants: WARP multipliers in double like the reference (integer division inside the log,
     //      rankfm/_rankfm.pyx:269 under cdivision=True), MT19937 seeding (mt19937ar.c:60-73)
@@ -281,35 +311,87 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, cfg->n_users,
                                                                                       cfg->n_items, ws.error_flags);
 
-    // ---- launch geometry
-    const int rows_per_wave = serial ? 1 : 64 / shape->group;
+    // ---- plan, part 1 (segments kernel): user segments.  A user of degree d is cut into ceil(d / 32) near-equal runs of
+    //      consecutive CSR positions; descriptors {user, first position, length} are built on the host from the offsets.
+    //      The plan lives in the persistent head of the workspace; `plan_token` (= segment count) says it is still valid.
+    int64_t n_segments = (cfg->plan_token > 0 && cfg->plan_token != kRowsPlan) ? cfg->plan_token : 0;
+    const bool build_plan = !serial && cfg->plan_token <= 0;
+    if (use_segments && build_plan) {
+        std::vector<int64_t> off((size_t)cfg->n_users + 1);
+        RFM_HIP(hipMemcpyAsync(off.data(), b->csr_offsets, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost, stream));
+        RFM_HIP(hipStreamSynchronize(stream));
+        if (off[cfg->n_users] != N) use_segments = false;            // lists hold more than this call's interactions
+    }
+    if (use_segments && build_plan) {
+        const std::vector<int64_t> off = [&]() {
+            std::vector<int64_t> o((size_t)cfg->n_users + 1);
+            hipMemcpy(o.data(), b->csr_offsets, sizeof(int64_t) * o.size(), hipMemcpyDeviceToHost);
+            return o;
+        }();
+        std::vector<int4> desc;
+        desc.reserve(max_segments(N, cfg->n_users));
+        for (int u = 0; u < cfg->n_users; ++u) {
+            const int64_t d = off[u + 1] - off[u];
+            if (d <= 0) continue;
+            const int64_t parts = (d + kSegmentRows - 1) / kSegmentRows;
+            for (int64_t p = 0; p < parts; ++p) {
+                const int64_t s0 = off[u] + d * p / parts, s1 = off[u] + d * (p + 1) / parts;
+                desc.push_back(make_int4(u, (int)s0, (int)(s1 - s0), 0));
+            }
+        }
+        n_segments = (int64_t)desc.size();
+        RFM_HIP(hipMemcpyAsync(ws.seg_desc, desc.data(), sizeof(int4) * desc.size(), hipMemcpyHostToDevice, stream));
+        RFM_HIP(hipMemsetAsync(ws.sw_csr, 0xFF, sizeof(float) * (size_t)N, stream));
+        sw_to_csr_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, b->sample_weight, (long long)N, b->csr_offsets,
+                                                                 b->csr_items, (unsigned int *)ws.sw_csr, ws.error_flags);
+        unsigned int flags = 0;
+        RFM_HIP(hipMemcpyAsync(&flags, ws.error_flags, sizeof flags, hipMemcpyDeviceToHost, stream));
+        RFM_HIP(hipStreamSynchronize(stream));                        // also: `desc` is pageable host memory
+        if (flags & 4u) {                                             // same length, different content: not this call's rows
+            use_segments = false;
+            RFM_HIP(hipMemsetAsync(ws.error_flags, 0, sizeof(unsigned int) * 4, stream));
+            degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, cfg->n_users,
+                                                                                              cfg->n_items, ws.error_flags);
+        }
+    }
+    const bool single_group = use_segments && (cfg->debug_flags & 1) != 0, fresh = (cfg->debug_flags & 2) != 0;
+    const sgd_launch_fn launch = use_segments ? shape->table()[4 + (feat ? 1 : 0) + (fresh ? 2 : 0)]
+                                              : shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
+
+    // ---- launch geometry.  unit of work = one interaction (rows kernel) or one user segment (segments kernel)
+    const int64_t units = use_segments ? n_segments : N;
+    const int groups_per_wave = serial ? 1 : 64 / shape->group;
     int grid = 1;
-    int64_t rows_per_launch = N > 0 ? N : 1;
+    int64_t units_per_launch = units > 0 ? units : 1;
     if (!serial) {
-        if (cfg->rows_per_launch > 0 && cfg->rows_per_launch < rows_per_launch) rows_per_launch = cfg->rows_per_launch;
-        const int64_t rows_per_block = (int64_t)rows_per_wave * 4;
-        const int64_t need = (rows_per_launch + rows_per_block - 1) / rows_per_block;
-        // Default concurrency: 4 workgroups of 4 wavefronts per CU (1024 workgroups, 16 k rows in flight on MI355X).
-        // Measured on BASELINE config 2 the update rate saturates there (profiles/r01_notes.md); more wavefronts only
-        // add staleness.  All workgroups are resident, so the wavefronts sweep the shuffled positions together and the
-        // realised order stays close to the sequential one.  Never keep more than 1/128 of an epoch in flight: every
-        // in-flight update reads weights that are stale by up to that many steps, and Hogwild only tracks sequential
-        // SGD while that window is a small fraction of the data (DESIGN.md "staleness").
+        if (cfg->rows_per_launch > 0 && cfg->rows_per_launch < N) {
+            units_per_launch = use_segments ? (int64_t)((double)cfg->rows_per_launch * (double)units / (double)N) : cfg->rows_per_launch;
+            if (units_per_launch < 1) units_per_launch = 1;
+        }
+        const int64_t groups_per_block = (int64_t)groups_per_wave * 4;
+        const int64_t need = (units_per_launch + groups_per_block - 1) / groups_per_block;
+        // Default concurrency: 4 workgroups of 4 wavefronts per CU (1024 workgroups, 16 k interactions in flight on
+        // MI355X).  Measured on BASELINE config 2 the update rate saturates there (profiles/); more wavefronts only add
+        // staleness.  All workgroups are resident, so they sweep the epoch's order together and the realised order stays
+        // close to the sequential one.  Never keep more than 1/128 of an epoch in flight: every in-flight update reads
+        // weights that are stale by up to that many steps, and Hogwild only tracks sequential SGD while that window is
+        // a small fraction of the data (DESIGN.md "staleness").
         int64_t cap = (int64_t)(g_sm_count > 0 ? g_sm_count : 256) * 4;
-        const int64_t window = (N / 128 + rows_per_block - 1) / rows_per_block;
+        const int64_t window = (N / 128 + groups_per_block - 1) / groups_per_block;
         if (window < cap) cap = window;
         if (cfg->n_workgroups > 0) cap = cfg->n_workgroups;
         grid = (int)(need < cap ? need : cap);
-        if (grid < 1) grid = 1;
+        if (grid < 1 || single_group) grid = 1;
     }
-    const int launches = (int)((N + rows_per_launch - 1) / rows_per_launch);
+    const int launches = (int)((units + units_per_launch - 1) / units_per_launch);
 
-    // ---- Hogwild damping plan: n(row) = in-flight rows x share of the data; scale = min(1, M / n) = min(1, cap / count)
+    // ---- plan, part 2: Hogwild damping.  n(row) = in-flight interactions x the row's share of the data;
+    //      scale = min(1, M / n) = min(1, cap / count)
     const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
-    const bool damp = !serial && damp_m > 0.0f && N > 0;
-    const long long in_flight = (long long)grid * 4 * rows_per_wave;
+    const bool damp = !serial && !single_group && damp_m > 0.0f && N > 0;
+    const long long in_flight = single_group ? 1 : (long long)grid * 4 * groups_per_wave;
     const float damp_cap = damp ? damp_m * (float)N / (float)in_flight : 0.0f;
-    if (damp && !cfg->plan_is_cached) {
+    if (damp && build_plan) {
         RFM_HIP(hipMemsetAsync(ws.pos_scale, 0, sizeof(float) * (size_t)cfg->n_items, stream));
         item_count_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, (long long)N, (int *)ws.pos_scale);
         item_scale_kernel<<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>((int *)ws.pos_scale, cfg->n_items, damp_cap);
@@ -334,6 +416,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.max_samples = cfg->max_samples; a.rng = cfg->rng;
         a.epoch_key = rfm_epoch_key(cfg->seed, (uint32_t)epoch);
         a.perm_bits = rfm_perm_bits((uint32_t)N);
+        a.sw_csr = ws.sw_csr; a.seg_desc = ws.seg_desc; a.n_segments = n_segments;
+        a.seg_bits = rfm_perm_bits((uint32_t)(n_segments > 0 ? n_segments : 1));
+        a.single_group = single_group ? 1 : 0;
         // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
         a.eta = cfg->learning_schedule == RFM_SCHEDULE_CONSTANT
                     ? cfg->learning_rate
@@ -349,9 +434,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
                                                 0.5f / ((float)in_flight * a.eta * fmaxf(a.reg_b, 1e-6f)))) : 1.0f;
 
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e], stream));
-        for (int64_t p0 = 0; p0 < N; p0 += rows_per_launch) {
+        for (int64_t p0 = 0; p0 < units; p0 += units_per_launch) {
             a.pos_begin = p0;
-            a.pos_end = p0 + rows_per_launch < N ? p0 + rows_per_launch : N;
+            a.pos_end = p0 + units_per_launch < units ? p0 + units_per_launch : units;
             launch(a, grid, stream);
         }
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));
@@ -417,7 +502,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->epochs_done = epochs_done;
         rep->nonfinite_array = bad_array;
         rep->launches_per_epoch = launches;
-        rep->waves_per_launch = grid * (serial ? 1 : 4);
+        rep->waves_per_launch = single_group ? 1 : grid * (serial ? 1 : 4);
+        rep->plan_token = serial || b->perms ? 0 : (use_segments ? n_segments : kRowsPlan);
     }
     if (timing)
         for (auto &e : ev) hipEventDestroy(e);

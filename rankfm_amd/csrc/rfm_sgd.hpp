@@ -1,24 +1,31 @@
-// rfm_sgd.hpp -- the BPR/WARP SGD wavefront kernel of the MI355X RankFM engine (gfx950 only).
+// rfm_sgd.hpp -- the BPR/WARP SGD wavefront kernels of the MI355X RankFM engine (gfx950 only).
 //
-// Replaces the reference's sequential row loop rankfm/_rankfm.pyx:230-326 (one SGD step per shuffled
-// interaction: score positive, draw/score negative(s), sigmoid gradient, in-place update of
-// w_i, w_if, v_u, v_i, v_uf, v_if) together with compute_ui_utility (:48-89), the rejection sampler
-// (:250-253 + lsearch :20-27) and the WARP early-exit loop (:244-270).
+// Replaces the reference's sequential row loop rankfm/_rankfm.pyx:230-326 (one SGD step per shuffled interaction:
+// score positive, draw/score negative(s), sigmoid gradient, in-place update of w_i, w_if, v_u, v_i, v_uf, v_if)
+// together with compute_ui_utility (:48-89), the rejection sampler (:250-253 + lsearch :20-27) and the WARP
+// early-exit loop (:244-270).
 //
 // Mapping onto CDNA4:
-//   * A "row group" of G lanes (G = 4..64, power of two) owns one interaction; lane s of the group owns
-//     factor chunks c = s, s+G, ... of VEC floats (VEC = 4 -> one 16-byte load per chunk, so a k=64 row
-//     is one fully coalesced 256-byte segment read by 16 lanes; VEC = 1 for factor counts that are not
-//     a multiple of 4).  A 64-lane wavefront therefore carries 64/G interactions at once.
-//   * The k-dimension dot products are xor-butterfly reductions inside the group (DPP / ds_bpermute);
-//     every lane ends with the bit-identical sum, so the WARP control flow is group-uniform.
+//   * A "row group" of G lanes (G = 16 for 16 <= F <= 128) owns one interaction; lane s of the group owns factor
+//     dwords s, s+G, s+2G, ...  Every load / atomic instruction of a group therefore covers ONE contiguous 64-byte
+//     segment of a factor row, and a wavefront carries 64/G interactions at once.  (The L2 atomic path is
+//     request-bound: 16-byte-per-lane chunks gave 4 dwords per 64-byte request and ran 3.4x slower, profiles/.)
+//   * The k-dimension dot products are xor-butterfly reductions inside the group (DPP / ds_bpermute); every lane
+//     ends with the bit-identical sum, so the WARP control flow is group-uniform.
 //   * Negative draws are counter based (include/rfm_rng.h): no shared RNG state, any lane can draw.
-//   * HOGWILD mode: factor/bias updates are fp32 hardware atomics (global_atomic_add_f32), computed as
-//     delta = eta * (grad - 2*reg*w_loaded) from the values the step loaded (the update is not a pure
-//     add, it reads w).  SERIAL mode: ONE wavefront, ONE group active, plain
-//     read-modify-write in the reference's exact order -- the reference's sequential semantics, used
-//     by the parity tests against the golden vectors and for debugging.
 //   * No MFMA anywhere: ~2 flops per 4-byte factor element; this is an HBM/L2 gather-scatter.
+//
+// Two kernels share the step (RowStep):
+//   sgd_rows_kernel      one interaction per group per iteration, positions of the epoch's shuffled order striding the
+//                        grid.  SERIAL instantiation: ONE wavefront, ONE group, plain read-modify-write in the reference's
+//                        exact order -- the reference's sequential semantics (golden-vector parity, debugging).  The
+//                        Hogwild instantiation is used when the caller dictates the visiting order (`perms`).
+//   sgd_segments_kernel  production Hogwild.  The unit of work is a user SEGMENT (<= 32 consecutive CSR rows of one
+//                        user): the group keeps v_u[u] in registers for the whole segment (read once, one atomic
+//                        delta write-back), walks the user's rows straight out of the CSR arrays (no interaction /
+//                        permutation / sample-weight gathers) and updates the two item rows with fp32 hardware
+//                        atomics (global_atomic_add_f32).  Segments are visited in a keyed pseudo-random order and rows
+//                        inside a segment in a keyed order (rfm_rng.h), both reproducible on the host.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,26 +35,29 @@
 namespace rfm {
 
 struct SgdArgs {
-    const int32_t *__restrict__ interactions;   // [N,2]
-    const float *__restrict__ sample_weight;    // [N]
+    const int32_t *__restrict__ interactions;   // [N,2]                         (rows kernel)
+    const float *__restrict__ sample_weight;    // [N]                           (rows kernel)
     const int64_t *__restrict__ csr_off;        // [U+1]
-    const int32_t *__restrict__ csr_items;      // [nnz]
+    const int32_t *__restrict__ csr_items;      // [nnz] positive items by CSR position, sorted within each user
     const float *__restrict__ x_uf;             // [U,P]
     const float *__restrict__ x_if;             // [I,Q]
     float *w_i, *w_if, *v_u, *v_i, *v_uf, *v_if;
-    const int32_t *__restrict__ perm;           // this epoch's visiting order [N] or nullptr
+    const int32_t *__restrict__ perm;           // this epoch's visiting order [N] or nullptr        (rows kernel)
+    const float *__restrict__ sw_csr;           // [N] sample weight by CSR position                 (segments kernel)
+    const int4 *__restrict__ seg_desc;          // [S] {user, first CSR position, length, 0}         (segments kernel)
     const float *__restrict__ multiplier;       // [max_samples+1]: log((I-1)/s)/log(I), s = 1..max_samples (host, double)
     uint32_t *mt_state;                         // [625] MT19937 words + index (serial + MT only)
     double *ll;                                 // this epoch's log-likelihood accumulator
     unsigned long long *draws;                  // this epoch's accepted-draw counter
     unsigned int *error_flags;                  // bit 0: rejection sampler gave up
-    int64_t pos_begin, pos_end;                 // positions of the epoch handled by this launch
+    int64_t pos_begin, pos_end;                 // positions (rows kernel) / segment-order positions (segments kernel)
     int64_t n_rows;                             // N
+    int64_t n_segments;                         // S
     int32_t n_items, n_uf, n_if, n_factors;     // I, P, Q, F
     int32_t has_uf, has_if;
     int32_t max_samples;
     int32_t rng;                                // RFM_RNG_*
-    uint32_t epoch_key, perm_bits;
+    uint32_t epoch_key, perm_bits, seg_bits;
     float eta, reg_a, reg_b;                    // learning rate of the epoch, 2*alpha, 2*beta
     // Hogwild step damping (DESIGN.md "staleness"): a row that n in-flight updates touch at once receives n steps computed
     // from the same stale value; above ~M of them the combined step overshoots.  The step on such a row is scaled by
@@ -55,11 +65,13 @@ struct SgdArgs {
     const float *__restrict__ pos_scale;        // [I] scale for the positive item's row (by item popularity), or nullptr
     float user_cap;                             // a user of degree d gets min(1, user_cap / d)
     float feat_scale;                           // scale for the dense feature tables (every row touches them)
-    int32_t update_mode;                        // hogwild experiments: 0 all atomics, 1 v_u plain RMW, 2 everything plain RMW
+    int32_t update_mode;                        // experiments: 0 all atomics, 1 v_u plain RMW, 2 everything plain RMW
+    int32_t single_group;                       // debug: only group 0 of wavefront 0 works (sequential Hogwild kernel)
 };
 
 constexpr float kMargin = 1.0f;                 // rankfm/_rankfm.pyx:149
 constexpr uint32_t kMaxAttempts = 1u << 22;     // safety net; the host rejects saturated users up front
+constexpr int kSegmentRows = 32;                // longest user segment (host planner uses the same constant)
 
 // ---------------------------------------------------------------------------------------------
 // small helpers
@@ -71,39 +83,21 @@ __device__ __forceinline__ float group_sum(float x) {
     return x;
 }
 
-template <int VEC>
-__device__ __forceinline__ void load_chunk(const float *p, float (&r)[VEC]) {
-    if constexpr (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4 *>(p);
-        r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
-    } else {
-        r[0] = *p;
-    }
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_chunk(float *p, const float (&r)[VEC]) {
-    if constexpr (VEC == 4) {
-        *reinterpret_cast<float4 *>(p) = make_float4(r[0], r[1], r[2], r[3]);
-    } else {
-        *p = r[0];
-    }
-}
-
 // fp32 hardware atomic add, no return value (global_atomic_add_f32)
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
 
-template <bool SERIAL, int VEC>
-__device__ __forceinline__ void apply_chunk(float *p, const float (&oldv)[VEC], const float (&delta)[VEC], bool plain = false) {
-    if (SERIAL || plain) {
-        float n[VEC];
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) n[e] = oldv[e] + delta[e];
-        store_chunk<VEC>(p, n);
-    } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) atomic_add_f32(p + e, delta[e]);
-    }
+// FRESH loads bypass the per-CU L1 (global_load_dword sc1): another CU's atomics are then visible as soon as they
+// have been performed, instead of whenever the L1 line happens to be evicted
+template <bool FRESH>
+__device__ __forceinline__ float load_f32(const float *p) {
+    if constexpr (FRESH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+template <bool PLAIN>
+__device__ __forceinline__ void apply_f32(float *p, float oldv, float delta, bool plain_rt = false) {
+    if (PLAIN || plain_rt) *p = oldv + delta;
+    else atomic_add_f32(p, delta);
 }
 
 // membership of `item` in the user's sorted list: the predicate of lsearch (rankfm/_rankfm.pyx:20-27),
@@ -145,58 +139,52 @@ __device__ __forceinline__ float log_sigmoid(float x) {
 
 // ---------------------------------------------------------------------------------------------
 // one SGD step for one interaction, executed by the G lanes of a row group
+//   SERIAL   plain read-modify-write everywhere, MT stream allowed
+//   VU_REGS  v_u lives in the caller's registers: the step updates them in place and does not touch v_u memory
+//   FRESH    item-row loads bypass L1
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int G, int KPL, bool SERIAL, bool FEAT>
+template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH>
 struct RowStep {
-    static constexpr int CH = KPL;   // chunks per lane
-
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
     const int F;
 
     __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_) : a(args), sub(sub_), F(args.n_factors) {}
 
-    __device__ __forceinline__ int chunk_f(int k) const { return (sub + G * k) * VEC; }
-    __device__ __forceinline__ bool chunk_ok(int k) const { return chunk_f(k) < F; }
+    __device__ __forceinline__ int dword_f(int k) const { return sub + G * k; }
+    __device__ __forceinline__ bool dword_ok(int k) const { return dword_f(k) < F; }
 
-    __device__ __forceinline__ void load_row(const float *base, float (&r)[KPL][VEC]) const {
+    template <bool FR>
+    __device__ __forceinline__ void load_row(const float *base, float (&r)[KPL]) const {
 #pragma unroll
-        for (int k = 0; k < KPL; ++k) {
-            if (chunk_ok(k)) {
-                load_chunk<VEC>(base + chunk_f(k), r[k]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) r[k][e] = 0.0f;
-            }
-        }
+        for (int k = 0; k < KPL; ++k) r[k] = dword_ok(k) ? load_f32<FR>(base + dword_f(k)) : 0.0f;
     }
 
-    // acc[f] = sum_r x[r] * table[r, f]   (feature projection into factor space, this lane's chunks)
-    __device__ __forceinline__ void project(const float *__restrict__ x, int n, const float *table,
-                                            float (&acc)[KPL][VEC]) const {
+    __device__ __forceinline__ void zero(float (&r)[KPL]) const {
 #pragma unroll
-        for (int k = 0; k < KPL; ++k)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[k][e] = 0.0f;
+        for (int k = 0; k < KPL; ++k) r[k] = 0.0f;
+    }
+
+    // acc[f] = sum_r x[r] * table[r, f]   (feature projection into factor space, this lane's dwords)
+    __device__ __forceinline__ void project(const float *__restrict__ x, int n, const float *table, float (&acc)[KPL]) const {
+        zero(acc);
         for (int r = 0; r < n; ++r) {
             const float xr = x[r];
             if (xr == 0.0f) continue;     // zero entries contribute nothing (and are skipped by the reference, :73,:81)
-            float t[KPL][VEC];
-            load_row(table + (size_t)r * F, t);
+            float t[KPL];
+            load_row<false>(table + (size_t)r * F, t);
 #pragma unroll
-            for (int k = 0; k < KPL; ++k)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[k][e] += xr * t[k][e];
+            for (int k = 0; k < KPL; ++k) acc[k] += xr * t[k];
         }
     }
 
     // compute_ui_utility (rankfm/_rankfm.pyx:48-89) for item `it` given the user-side registers:
     //   w_i[it] + sum_q x_if[it,q] w_if[q] + sum_f [ (vu_f + A_f) * vi_f + B_f(it) * vu_f ]
     // A = x_uf[u] . v_uf  (user-feature projection), B(it) = x_if[it] . v_if  (item-feature projection)
-    __device__ __forceinline__ float utility(const float (&vu)[KPL][VEC], const float (&A)[KPL][VEC], int32_t it,
-                                             float (&vi)[KPL][VEC], float (&B)[KPL][VEC], float &wi) const {
-        load_row(a.v_i + (size_t)it * F, vi);
-        wi = a.w_i[it];
+    __device__ __forceinline__ float utility(const float (&vu)[KPL], const float (&A)[KPL], int32_t it, float (&vi)[KPL],
+                                             float (&B)[KPL], float &wi) const {
+        load_row<FRESH>(a.v_i + (size_t)it * F, vi);
+        wi = load_f32<FRESH>(a.w_i + it);
         float part = 0.0f, scalar = 0.0f;
         if constexpr (FEAT) {
             if (a.has_if) {
@@ -204,20 +192,13 @@ struct RowStep {
                 project(xi, a.n_if, a.v_if, B);
                 for (int q = 0; q < a.n_if; ++q) scalar += xi[q] * a.w_if[q];
             } else {
-#pragma unroll
-                for (int k = 0; k < KPL; ++k)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) B[k][e] = 0.0f;
+                zero(B);
             }
 #pragma unroll
-            for (int k = 0; k < KPL; ++k)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) part += (vu[k][e] + A[k][e]) * vi[k][e] + B[k][e] * vu[k][e];
+            for (int k = 0; k < KPL; ++k) part += (vu[k] + A[k]) * vi[k] + B[k] * vu[k];
         } else {
 #pragma unroll
-            for (int k = 0; k < KPL; ++k)
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) part += vu[k][e] * vi[k][e];
+            for (int k = 0; k < KPL; ++k) part += vu[k] * vi[k];
         }
         return wi + scalar + group_sum<G>(part);
     }
@@ -241,46 +222,34 @@ struct RowStep {
         return j;
     }
 
-    __device__ __forceinline__ void operator()(int64_t row, double &ll_acc, unsigned &draw_acc) const {
-        const int32_t u = a.interactions[2 * row];                       // :233-235
-        const int32_t i = a.interactions[2 * row + 1];
-        const float sw = a.sample_weight[row];                           // :236
-        const int64_t lo = a.csr_off[u], hi = a.csr_off[u + 1];
-        const uint32_t row_key = rfm_row_key(a.epoch_key, (uint32_t)row);
+    // `vu` holds v_u[u] on entry; with VU_REGS it holds the updated row on exit
+    __device__ __forceinline__ void operator()(uint32_t row_key, int32_t u, int32_t i, float sw, int64_t lo, int64_t hi,
+                                               float (&vu)[KPL], double &ll_acc, unsigned &draw_acc) const {
         uint32_t attempt = 0;
-
-        float vu[KPL][VEC], A[KPL][VEC];
-        load_row(a.v_u + (size_t)u * F, vu);
+        float A[KPL];
         if constexpr (FEAT) {
             if (a.has_uf) project(a.x_uf + (size_t)u * a.n_uf, a.n_uf, a.v_uf, A);
-            else {
-#pragma unroll
-                for (int k = 0; k < KPL; ++k)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) A[k][e] = 0.0f;
-            }
+            else zero(A);
         }
 
-        float vi[KPL][VEC], Bi[KPL][VEC], wi;
+        float vi[KPL], Bi[KPL], wi;
         const float ut_ui = utility(vu, A, i, vi, Bi, wi);               // :239
 
         // WARP sampling loop (:244-264); BPR is max_samples == 1
-        float vj[KPL][VEC], Bj[KPL][VEC], wj = 0.0f;
+        float vj[KPL], Bj[KPL], wj = 0.0f;
         float min_pu = 1e6f;
         int32_t j = -1;
         int sampled = 0;
         for (int s = 1; s <= a.max_samples; ++s) {
             const int32_t cand = next_negative(lo, hi, row_key, attempt);
-            float vc[KPL][VEC], Bc[KPL][VEC], wc;
+            float vc[KPL], Bc[KPL], wc;
             const float pu = ut_ui - utility(vu, A, cand, vc, Bc, wc);   // :256-257
             sampled = s;
             if (pu < min_pu || j < 0) {                                   // :259-261 (j < 0: keep a valid index under NaN)
                 if (pu < min_pu) min_pu = pu;
                 j = cand; wj = wc;
 #pragma unroll
-                for (int k = 0; k < KPL; ++k)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) { vj[k][e] = vc[k][e]; if constexpr (FEAT) Bj[k][e] = Bc[k][e]; }
+                for (int k = 0; k < KPL; ++k) { vj[k] = vc[k]; if constexpr (FEAT) Bj[k] = Bc[k]; }
             }
             if (pu < kMargin) break;                                      // :263-264
         }
@@ -296,13 +265,14 @@ struct RowStep {
             if (a.pos_scale) eta_i = eta * a.pos_scale[i];
             eta_f = eta * a.feat_scale;
         }
+        const bool plain_items = !SERIAL && a.update_mode >= 2, plain_user = !SERIAL && a.update_mode >= 1;
 
         // item biases (:279-280) -- one lane per group
         if (sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
-            if constexpr (SERIAL) { a.w_i[i] = wi + dwi; a.w_i[j] = wj + dwj; }
-            else { atomic_add_f32(a.w_i + i, dwi); atomic_add_f32(a.w_i + j, dwj); }
+            apply_f32<SERIAL>(a.w_i + i, wi, dwi, plain_items);
+            apply_f32<SERIAL>(a.w_i + j, wj, dwj, plain_items);
         }
 
         // item-feature weights (:283-286): every q shrinks, lanes split the q range
@@ -311,34 +281,33 @@ struct RowStep {
                 const float *xi = a.x_if + (size_t)i * a.n_if, *xj = a.x_if + (size_t)j * a.n_if;
                 for (int q = sub; q < a.n_if; q += G) {
                     const float w = a.w_if[q];
-                    const float d = eta_f * (g * (d_outer * (xi[q] - xj[q])) - reg_b * w);
-                    if constexpr (SERIAL) a.w_if[q] = w + d; else atomic_add_f32(a.w_if + q, d);
+                    apply_f32<SERIAL>(a.w_if + q, w, eta_f * (g * (d_outer * (xi[q] - xj[q])) - reg_b * w));
                 }
             }
         }
 
-        // factor updates (:289-326), this lane's chunks
-        float nvu[KPL][VEC], dij[KPL][VEC];     // updated v_u, updated (v_i - v_j)
+        // factor updates (:289-326), this lane's dwords
+        float nvu[KPL], dij[KPL];     // updated v_u, updated (v_i - v_j)
 #pragma unroll
         for (int k = 0; k < KPL; ++k) {
-            float d_u[VEC], d_i[VEC], d_j[VEC];
+            float g_u = vi[k] - vj[k];                                    // :292
+            float g_i = vu[k];                                            // :293-294 (d_v_j = -d_v_i)
+            if constexpr (FEAT) { g_i += A[k]; g_u += Bi[k] - Bj[k]; }   // :297-305
+            const float d_u = eta_u * (g * (d_outer * g_u) - reg_a * vu[k]);   // :308
+            const float d_i = eta_i * (g * (d_outer * g_i) - reg_a * vi[k]);   // :309
+            const float d_j = eta * (g * (d_outer * -g_i) - reg_a * vj[k]);    // :310
+            nvu[k] = vu[k] + d_u;
+            dij[k] = (vi[k] + d_i) - (vj[k] + d_j);
+            if (dword_ok(k)) {
+                const int f = dword_f(k);
+                if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u, plain_user);
+                apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i, plain_items);
+                apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
+            }
+        }
+        if constexpr (VU_REGS) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float g_u = vi[k][e] - vj[k][e];                          // :292
-                float g_i = vu[k][e];                                     // :293-294 (d_v_j = -d_v_i)
-                if constexpr (FEAT) { g_i += A[k][e]; g_u += Bi[k][e] - Bj[k][e]; }   // :297-305
-                d_u[e] = eta_u * (g * (d_outer * g_u) - reg_a * vu[k][e]);  // :308
-                d_i[e] = eta_i * (g * (d_outer * g_i) - reg_a * vi[k][e]);  // :309
-                d_j[e] = eta * (g * (d_outer * -g_i) - reg_a * vj[k][e]); // :310
-                nvu[k][e] = vu[k][e] + d_u[e];
-                dij[k][e] = (vi[k][e] + d_i[e]) - (vj[k][e] + d_j[e]);
-            }
-            if (chunk_ok(k)) {
-                const int f0 = chunk_f(k);
-                apply_chunk<SERIAL, VEC>(a.v_u + (size_t)u * F + f0, vu[k], d_u, a.update_mode >= 1);
-                apply_chunk<SERIAL, VEC>(a.v_i + (size_t)i * F + f0, vi[k], d_i, a.update_mode >= 2);
-                apply_chunk<SERIAL, VEC>(a.v_i + (size_t)j * F + f0, vj[k], d_j, a.update_mode >= 2);
-            }
+            for (int k = 0; k < KPL; ++k) vu[k] = nvu[k];
         }
 
         if constexpr (FEAT) {
@@ -351,12 +320,9 @@ struct RowStep {
                     float *trow = a.v_uf + (size_t)p * F;
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
-                        if (!chunk_ok(k)) continue;
-                        float t[VEC], d[VEC];
-                        load_chunk<VEC>(trow + chunk_f(k), t);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) d[e] = eta_f * (g * (d_outer * (xp * dij[k][e])) - reg_b * t[e]);
-                        apply_chunk<SERIAL, VEC>(trow + chunk_f(k), t, d);
+                        if (!dword_ok(k)) continue;
+                        const float t = trow[dword_f(k)];
+                        apply_f32<SERIAL>(trow + dword_f(k), t, eta_f * (g * (d_outer * (xp * dij[k])) - reg_b * t));
                     }
                 }
             }
@@ -369,12 +335,9 @@ struct RowStep {
                     float *trow = a.v_if + (size_t)q * F;
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
-                        if (!chunk_ok(k)) continue;
-                        float t[VEC], d[VEC];
-                        load_chunk<VEC>(trow + chunk_f(k), t);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) d[e] = eta_f * (g * (d_outer * (dx * nvu[k][e])) - reg_b * t[e]);
-                        apply_chunk<SERIAL, VEC>(trow + chunk_f(k), t, d);
+                        if (!dword_ok(k)) continue;
+                        const float t = trow[dword_f(k)];
+                        apply_f32<SERIAL>(trow + dword_f(k), t, eta_f * (g * (d_outer * (dx * nvu[k])) - reg_b * t));
                     }
                 }
             }
@@ -382,17 +345,31 @@ struct RowStep {
     }
 };
 
+// wavefront reduction of the log-likelihood / draw counters, one atomic each per wavefront
+__device__ __forceinline__ void flush_counters(const SgdArgs &a, double ll_acc, unsigned draw_acc) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        ll_acc += __shfl_xor(ll_acc, m);
+        draw_acc += __shfl_xor(draw_acc, m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (ll_acc != 0.0) unsafeAtomicAdd(a.ll, ll_acc);
+        if (draw_acc) atomicAdd(a.draws, (unsigned long long)draw_acc);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// the kernel: every wavefront walks the epoch's positions with a grid stride of (waves * rows-per-wave)
+// rows kernel: every wavefront walks the epoch's positions with a grid stride of (waves * rows-per-wave)
 // ---------------------------------------------------------------------------------------------
-template <int VEC, int G, int KPL, bool SERIAL, bool FEAT>
-__global__ void __launch_bounds__(256) sgd_kernel(const SgdArgs a) {
+template <int G, int KPL, bool SERIAL, bool FEAT>
+__global__ void __launch_bounds__(256) sgd_rows_kernel(const SgdArgs a) {
     constexpr int RPW = SERIAL ? 1 : 64 / G;                    // interactions carried by one wavefront at a time
     const int lane = threadIdx.x & 63;
     const int grp = lane / G, sub = lane % G;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const RowStep<VEC, G, KPL, SERIAL, FEAT> step(a, sub);
+    const RowStep<G, KPL, SERIAL, FEAT, false, false> step(a, sub);
+    const int F = a.n_factors;
 
     double ll_acc = 0.0;
     unsigned draw_acc = 0;
@@ -402,23 +379,84 @@ __global__ void __launch_bounds__(256) sgd_kernel(const SgdArgs a) {
         if (active) {
             const int64_t row = a.perm ? (int64_t)a.perm[pos]
                                        : (int64_t)rfm_perm((uint32_t)pos, (uint32_t)a.n_rows, a.perm_bits, a.epoch_key);
-            step(row, ll_acc, draw_acc);
-        }
-    }
-    // wavefront reduction of the log-likelihood / draw counters, one atomic each per wavefront
+            const int32_t u = a.interactions[2 * row];                       // :233-235
+            const int32_t i = a.interactions[2 * row + 1];
+            const float sw = a.sample_weight[row];                           // :236
+            const int64_t lo = a.csr_off[u], hi = a.csr_off[u + 1];
+            float vu[KPL];
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        ll_acc += __shfl_xor(ll_acc, m);
-        draw_acc += __shfl_xor(draw_acc, m);
+            for (int k = 0; k < KPL; ++k) vu[k] = (sub + G * k < F) ? a.v_u[(size_t)u * F + sub + G * k] : 0.0f;
+            step(rfm_row_key(a.epoch_key, (uint32_t)row), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+        }
+        if constexpr (SERIAL) __threadfence_block();   // row r+1 must observe row r (cross-lane w_i / w_if reads)
     }
-    if (lane == 0) {
-        if (ll_acc != 0.0) unsafeAtomicAdd(a.ll, ll_acc);
-        if (draw_acc) atomicAdd(a.draws, (unsigned long long)draw_acc);
-    }
+    flush_counters(a, ll_acc, draw_acc);
 }
 
-// host-side launcher table (rfm_sgd_inst_*.hip)
+// ---------------------------------------------------------------------------------------------
+// segments kernel (production Hogwild): see the header comment.  Each group is a little state machine
+//   [fetch segment + v_u] -> row, row, ... -> [write back v_u delta] -> next segment
+// so the four groups of a wavefront stay busy although their segments differ in length.
+// ---------------------------------------------------------------------------------------------
+template <int G, int KPL, bool FEAT, bool FRESH>
+__global__ void __launch_bounds__(256) sgd_segments_kernel(const SgdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
+    const RowStep<G, KPL, false, FEAT, true, FRESH> step(a, sub);
+    const int F = a.n_factors;
+
+    double ll_acc = 0.0;
+    unsigned draw_acc = 0;
+    int64_t sp = a.pos_begin + (a.single_group ? 0 : group);      // position in the epoch's segment order
+    const int64_t stride = a.single_group ? 1 : n_groups;
+    bool active = sp < a.pos_end && (!a.single_group || group == 0);
+    bool have = false;
+    int32_t u = 0, begin = 0, len = 0, t = 0, len_bits = 0;
+    uint32_t seg_key = 0;
+    int64_t lo = 0, hi = 0;
+    float vu[KPL], vu0[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
+
+    while (__any(active)) {
+        if (active && !have) {
+            const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
+            const int4 d = a.seg_desc[seg];
+            u = d.x; begin = d.y; len = d.z;
+            lo = a.csr_off[u]; hi = a.csr_off[u + 1];
+            len_bits = (int32_t)rfm_perm_bits((uint32_t)len);
+            seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                vu[k] = vu0[k];
+            }
+            t = 0;
+            have = true;
+        }
+        if (active) {
+            const int32_t pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);
+            const int32_t i = a.csr_items[pos];
+            const float sw = a.sw_csr[pos];
+            step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+            if (++t == len) {
+                // one write-back per segment; other segments of a heavy user may be in flight, so add the delta
+#pragma unroll
+                for (int k = 0; k < KPL; ++k)
+                    if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                have = false;
+                sp += stride;
+                active = sp < a.pos_end;
+            }
+        }
+    }
+    flush_counters(a, ll_acc, draw_acc);
+}
+
+// host-side launcher table (rfm_sgd_inst_*.hip): [0..3] rows kernel {hogwild, hogwild+feat, serial, serial+feat},
+// [4..7] segments kernel {plain, feat, fresh, fresh+feat}
 typedef void (*sgd_launch_fn)(const SgdArgs &, int grid, hipStream_t);
-struct SgdShape { int vec, group, kpl; };
 
 }  // namespace rfm

@@ -19,7 +19,7 @@ class DeviceSession:
                  learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25, max_samples=1,
                  mode="hogwild", rng="counter", seed=1492, device=None, n_workgroups=0, rows_per_launch=0,
                  check_finite=True, want_penalty=False, has_user_features=None, has_item_features=None,
-                 update_mode=0, shape_override=0, hogwild_damping=0.0):
+                 update_mode=0, shape_override=0, hogwild_damping=0.0, debug_flags=0):
         if not torch.cuda.is_available():
             raise _hip.EngineUnavailable("no MI355X visible to PyTorch-ROCm: rankfm_amd has no CPU fallback")
         _hip.lib()
@@ -63,11 +63,12 @@ class DeviceSession:
         self.update_mode = int(update_mode)
         self.shape_override = int(shape_override)
         self.hogwild_damping = float(hogwild_damping)
-        self._plan_cached = False
+        self._plan_token = 0
+        self.debug_flags = int(debug_flags)
 
     def _config(self, epochs, epoch_begin):
         return _hip.FitConfig(
-            hogwild_damping=self.hogwild_damping, plan_is_cached=int(self._plan_cached),
+            hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token), debug_flags=self.debug_flags,
             debug_update_mode=self.update_mode, debug_shape=self.shape_override,
             n_interactions=self.n_interactions, n_users=self.n_users, n_items=self.n_items,
             n_user_features=self.n_user_features, n_item_features=self.n_item_features, n_factors=self.n_factors,
@@ -84,8 +85,8 @@ class DeviceSession:
             _hip.raise_for_status(_hip.lib().rfm_fit_supported(C.byref(cfg)))
         if self._workspace is None or self._workspace.numel() < need:
             self._workspace = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-            self._plan_cached = False
-            cfg.plan_is_cached = 0
+            self._plan_token = 0
+            cfg.plan_token = 0
         perms_t = None
         if perms is not None:
             perms_t = torch.as_tensor(np.ascontiguousarray(perms, dtype=np.int32)).to(self.device)
@@ -109,7 +110,7 @@ class DeviceSession:
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = _hip.lib().rfm_fit_device(C.byref(cfg), C.byref(buf), C.c_void_p(stream), C.byref(rep))
-        self._plan_cached = (rc == _hip.OK)
+        self._plan_token = int(rep.plan_token) if (rc == _hip.OK and perms is None) else 0
         out = dict(status=rc, log_likelihood=ll, reg_penalty=pen, sgd_kernel_ms=ms, n_draws=draws,
                    epochs_done=rep.epochs_done, launches_per_epoch=rep.launches_per_epoch,
                    waves_per_launch=rep.waves_per_launch)

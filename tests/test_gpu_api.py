@@ -1,0 +1,167 @@
+"""Public-API conformance on the GPU: the behaviours the reference's own test-suite checks (tests/test_rankfm.py, 23 cases
+on a 3x6 toy set) re-expressed against rankfm_amd.RankFM on our own toy data, plus end-to-end parity with the reference
+through the golden api_*.npz fixtures (fit -> predict -> recommend -> evaluation)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import WEIGHTS, load_golden
+
+pytestmark = pytest.mark.gpu
+
+INTX = pd.DataFrame([(10, 1), (10, 3), (10, 5), (20, 1), (20, 2), (20, 6), (30, 3), (30, 6), (30, 4)], columns=["user_id", "item_id"])
+INTX_STR = pd.DataFrame({"user_id": INTX.user_id.map({10: "X", 20: "Y", 30: "Z"}), "item_id": INTX.item_id.map(lambda i: "ABCDEF"[i - 1])})
+UF = pd.DataFrame([(10, 0, 1, 5, 3.1), (20, 1, 0, 6, 2.7), (30, 0, 0, 4, 1.6)], columns=["user_id", "b1", "b2", "n", "c"])
+IF = pd.DataFrame([(1, 0, 1, 5, 3.1), (2, 1, 0, 6, 2.7), (3, 0, 0, 4, 1.6), (4, 1, 1, 3, 1.0), (5, 1, 0, 6, 0.3), (6, 0, 0, 0, 0.0)],
+                  columns=["item_id", "b1", "b2", "n", "c"])
+DISJOINT = pd.DataFrame([(10, 1), (10, 3), (10, 5), (20, 1), (20, 2), (20, 7), (40, 3), (40, 7), (40, 4)], columns=["user_id", "item_id"])
+TRAIN_USERS, VALID_USERS = np.array([10, 20, 30]), np.array([10, 20, 40, 50])
+
+
+def _model(**kw):
+    from rankfm_amd import RankFM
+    return RankFM(factors=2, **kw)
+
+
+@pytest.mark.parametrize("intx, uf, itf", [(INTX, None, None), (INTX_STR, None, None), (INTX.values, None, None),
+                                           (INTX, UF, None), (INTX, None, IF), (INTX, UF, IF), (INTX, UF.values, IF.values)])
+@pytest.mark.parametrize("loss", ["bpr", "warp"])
+def test_fit_accepts_the_reference_input_kinds(intx, uf, itf, loss, capsys):
+    m = _model(loss=loss, max_samples=3).fit(intx, uf, itf, epochs=2, verbose=True)
+    assert m.is_fit and capsys.readouterr().out.count("training epoch:") == 2
+    for k in WEIGHTS:
+        w = getattr(m, k)
+        assert w.dtype == np.float32 and w.flags.c_contiguous and np.isfinite(w).all()
+    assert m.v_u.shape == (3, 2) and m.v_i.shape == (6, 2) and m.w_i.shape == (6,)
+
+
+def test_fit_partial_and_sample_weight():
+    m = _model().fit(INTX, sample_weight=np.linspace(0.5, 1.5, 9).astype(np.float32), epochs=1)
+    before = m.v_u.copy()
+    m.fit_partial(INTX.iloc[:5], epochs=2)
+    assert m.is_fit and not np.array_equal(before, m.v_u) and m.epochs_trained == 3
+    assert len(m.interactions) == 5 and m.user_items[0].tolist() == [0, 2, 4]
+
+
+def test_predict_shapes_dtypes_and_cold_start():
+    m = _model().fit(INTX)
+    s = m.predict(INTX)
+    assert s.shape == (9,) and s.dtype == np.float32 and not np.isnan(s).any()
+    s = m.predict(DISJOINT, cold_start="nan")
+    assert s.shape == (9,) and s.dtype == np.float32 and int(np.isnan(s).sum()) == 4
+    s = m.predict(DISJOINT, cold_start="drop")
+    assert s.shape == (5,) and not np.isnan(s).any()
+    with pytest.raises(ValueError):
+        m.predict(INTX, cold_start="zero")
+    # the score is the reference's pointwise utility (rankfm/_rankfm.pyx:48-89) without features
+    u, i = m.user_to_index.loc[20], m.item_to_index.loc[6]
+    assert m.predict(np.array([[20, 6]]))[0] == pytest.approx(m.w_i[i] + m.v_u[u] @ m.v_i[i], abs=1e-6)
+
+
+def test_recommend_frames_filtering_and_cold_start():
+    m = _model().fit(INTX)
+    recs = m.recommend(TRAIN_USERS, n_items=3)
+    assert isinstance(recs, pd.DataFrame) and recs.shape == (3, 3) and np.array_equal(recs.index.values, TRAIN_USERS)
+    assert recs.isin(INTX.item_id.values).all().all()
+    assert all(len(set(r)) == 3 for r in recs.values)
+    recs = m.recommend(TRAIN_USERS, n_items=3, filter_previous=True)
+    long = recs.stack().reset_index().drop("level_1", axis=1)
+    long.columns = ["user_id", "item_id"]
+    assert pd.merge(INTX, long.astype({"item_id": INTX.item_id.dtype}), on=["user_id", "item_id"]).empty
+    recs = m.recommend(VALID_USERS, n_items=3, cold_start="nan")
+    assert recs.shape == (4, 3) and recs.loc[[40, 50]].isnull().all().all() and recs.dropna().isin(INTX.item_id.values).all().all()
+    recs = m.recommend(VALID_USERS, n_items=3, cold_start="drop")
+    assert recs.shape == (2, 3) and sorted(recs.index.values) == [10, 20]
+    # ranking really is by descending utility
+    top = m.recommend([30], n_items=6).values[0]
+    scores = m.predict(np.stack([np.full(6, 30), top], 1))
+    assert np.all(np.diff(scores) <= 1e-7)
+
+
+def test_similar_items_and_users():
+    m = _model().fit(INTX, UF, IF)
+    sim = m.similar_items(1, n_items=3)
+    assert sim.shape == (3,) and np.isin(sim, INTX.item_id.unique()).all() and 1 not in sim
+    sim = m.similar_users(10, n_users=2)
+    assert sim.shape == (2,) and np.isin(sim, INTX.user_id.unique()).all() and 10 not in sim
+    with pytest.raises(AssertionError):
+        m.similar_items(99)
+    with pytest.raises(AssertionError):
+        m.similar_users(9)
+
+
+def _golden_frames(g):
+    train = pd.DataFrame({"user_id": g["train_users"], "item_id": g["train_items"]})
+    test = pd.DataFrame({"user_id": g["test_users"], "item_id": g["test_items"]})
+    uf = itf = None
+    if int(g["with_features"]):
+        uf = pd.concat([pd.DataFrame({"user_id": g["uf_ids"]}), pd.DataFrame(g["uf_vals"])], axis=1)
+        itf = pd.concat([pd.DataFrame({"item_id": g["if_ids"]}), pd.DataFrame(g["if_vals"])], axis=1)
+    return train, test, uf, itf
+
+
+@pytest.mark.parametrize("case", ["bpr_int_nofeat", "warp_str_feat"])
+def test_end_to_end_drop_in_reproduces_the_reference(case):
+    """np.random.seed(21); RankFM(...).fit(...) with REFERENCE_ENGINE must reproduce the reference's fit() -- same initial
+    weights (numpy stream), same shuffles (continuing stream), same MT19937 negatives -- to fp32 tolerance, and then the
+    reference's predict / recommend / hit_rate / MRR / DCG / precision / recall outputs on it."""
+    from rankfm_amd import REFERENCE_ENGINE, RankFM, evaluation
+    g = load_golden("api", case)
+    train, test, uf, itf = _golden_frames(g)
+    m = RankFM(factors=int(g["factors"]), loss=str(g["loss"]), max_samples=int(g["max_samples"]), learning_schedule="invscaling",
+               engine=REFERENCE_ENGINE)
+    np.random.seed(21)
+    m.fit(train, uf, itf, g["train_sw"], epochs=int(g["epochs"]))
+    for k in WEIGHTS:
+        np.testing.assert_allclose(getattr(m, k), g["final_" + k], rtol=1e-4, atol=2e-5, err_msg=k)
+
+    # scoring / ranking kernels on the reference's own final weights (isolates _predict/_recommend from training noise)
+    for k in WEIGHTS:
+        setattr(m, k, np.ascontiguousarray(g["final_" + k]))
+    pred = pd.DataFrame({"user_id": g["pred_users"], "item_id": g["pred_items"]})
+    s = m.predict(pred)
+    assert np.array_equal(np.isnan(s), np.isnan(g["pred_scores"]))
+    np.testing.assert_allclose(s[~np.isnan(s)], g["pred_scores"][~np.isnan(s)], rtol=1e-5, atol=1e-6)
+    str_ids = bool(int(g["str_ids"]))
+    for key, flt in (("rec_all", False), ("rec_new", True)):
+        recs = m.recommend(list(g["rec_users"]), n_items=7, filter_previous=flt)
+        got = recs.values.astype("U16") if str_ids else recs.values.astype(np.float64)
+        want = g[key]
+        if str_ids:
+            assert np.array_equal(got, want), key
+        else:
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]), key
+    assert evaluation.hit_rate(m, test, k=7) == pytest.approx(float(g["hit_rate"]), abs=1e-12)
+    assert evaluation.hit_rate(m, test, k=7, filter_previous=True) == pytest.approx(float(g["hit_rate_new"]), abs=1e-12)
+    assert evaluation.reciprocal_rank(m, test, k=7) == pytest.approx(float(g["reciprocal_rank"]), abs=1e-9)
+    assert evaluation.discounted_cumulative_gain(m, test, k=7) == pytest.approx(float(g["dcg"]), abs=1e-9)
+    assert evaluation.precision(m, test, k=7) == pytest.approx(float(g["precision"]), abs=1e-9)
+    assert evaluation.recall(m, test, k=7) == pytest.approx(float(g["recall"]), abs=1e-9)
+
+
+def test_predict_and_recommend_match_oracle_at_scale(oracle):
+    """scoring kernels vs the CPU oracle on a mid-size model with features and NaN (cold-start) entries"""
+    from rankfm_amd import synthetic
+    from rankfm_amd._rankfm import _predict, _recommend
+    U, I, F, P, Q = 1500, 900, 24, 5, 6
+    rng = np.random.default_rng(3)
+    pairs, csr = synthetic.make_interactions(U, I, 40000, seed=1)
+    w = synthetic.init_weights(U, I, F, P, Q, sigma=0.5, seed=2)
+    w["w_i"] = rng.normal(0, 0.3, I).astype(np.float32)
+    w["w_if"] = rng.normal(0, 0.3, Q).astype(np.float32)
+    x_uf, x_if = synthetic.make_features(U, P, 4), synthetic.make_features(I, Q, 5)
+    args = (x_uf, x_if, w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"])
+    idx = np.stack([rng.integers(0, U, 5000), rng.integers(0, I, 5000)], 1).astype(np.float32)
+    idx[::97, 0] = np.nan
+    idx[::89, 1] = np.nan
+    s, so = _predict(idx, *args), oracle.predict(idx, *args)
+    assert np.array_equal(np.isnan(s), np.isnan(so))
+    np.testing.assert_allclose(s[~np.isnan(s)], so[~np.isnan(so)], rtol=1e-5, atol=2e-5)
+    users = rng.integers(0, U, 64).astype(np.float32)
+    users[5] = np.nan
+    for flt in (False, True):
+        rec = _recommend(users, csr, 10, flt, *args)
+        ro = oracle.recommend(users, csr.offsets, csr.items, 10, flt, *args)
+        assert np.isnan(rec[5]).all() and np.isnan(ro[5]).all()
+        same = rec[~np.isnan(users)] == ro[~np.isnan(users)]
+        assert same.mean() > 0.995          # identical up to fp32 near-ties in the ranking
