@@ -167,6 +167,7 @@ struct Workspace {
     unsigned int *error_flags;    // [1] (+pad)
     uint32_t *mt_state;           // [625] (+pad)
     float *multiplier;            // [max_samples + 1]
+    float *feat_snapshot;         // [(P+Q)*F + Q] feature tables at launch start (LDS-replica merge)
     size_t bytes;
 };
 
@@ -174,7 +175,7 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static size_t max_segments(int64_t n_rows, int n_users) { return (size_t)n_users + (size_t)(n_rows / kSegmentRows) + 1; }
 
-static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows) {
+static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_feat_tab) {
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
@@ -189,9 +190,15 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.error_flags = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int) * 4);
     w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
     w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
+    w.feat_snapshot = (float *)(p + o);          o += align_up(sizeof(float) * n_feat_tab);
     w.bytes = o;
     return w;
 }
+
+static size_t feat_table_floats(const rfm_fit_config *c) {
+    return (size_t)(c->n_user_features + c->n_item_features) * (size_t)c->n_factors + (size_t)c->n_item_features;
+}
+constexpr size_t kMaxLdsTableFloats = 16384;      // 64 KiB of LDS per workgroup for the feature-table replica
 
 static int validate(const rfm_fit_config *c) {
     if (!c) return RFM_ERR_BAD_ARG;
@@ -268,7 +275,7 @@ int rfm_fit_supported(const rfm_fit_config *cfg) { return validate(cfg); }
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
-    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions).bytes;
+    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_table_floats(cfg)).bytes;
 }
 
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
@@ -281,7 +288,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     if ((rc = device_ok()) != RFM_OK) return rc;
     const int E = cfg->epochs;
     const int64_t N = cfg->n_interactions;
-    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N);
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_table_floats(cfg));
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
@@ -292,7 +299,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // not (fit_partial keeps earlier items in the lists, rankfm/rankfm.py:170-172) or the caller dictates the order, the
     // rows kernel runs instead.  kRowsPlan marks such a plan in plan_token.
     constexpr int64_t kRowsPlan = (int64_t)1 << 62;
-    bool use_segments = !serial && !b->perms && N > 0 && cfg->plan_token != kRowsPlan;
+    bool use_segments = !serial && !b->perms && N > 0 && cfg->plan_token != kRowsPlan &&
+                        (!feat || feat_table_floats(cfg) <= kMaxLdsTableFloats);
 
     // ---- host-side constants: WARP multipliers in double like the reference (integer division inside the log,
     //      rankfm/_rankfm.pyx:269 under cdivision=True), MT19937 seeding (mt19937ar.c:60-73)
@@ -361,6 +369,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // ---- launch geometry.  unit of work = one interaction (rows kernel) or one user segment (segments kernel)
     const int64_t units = use_segments ? n_segments : N;
     const int groups_per_wave = serial ? 1 : 64 / shape->group;
+    const int waves_per_block = serial ? 1 : (use_segments && feat ? 16 : 4);      // see sgd_segments_kernel
     int grid = 1;
     int64_t units_per_launch = units > 0 ? units : 1;
     if (!serial) {
@@ -368,20 +377,33 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             units_per_launch = use_segments ? (int64_t)((double)cfg->rows_per_launch * (double)units / (double)N) : cfg->rows_per_launch;
             if (units_per_launch < 1) units_per_launch = 1;
         }
-        const int64_t groups_per_block = (int64_t)groups_per_wave * 4;
-        const int64_t need = (units_per_launch + groups_per_block - 1) / groups_per_block;
+        const int64_t groups_per_block = (int64_t)groups_per_wave * waves_per_block;
+        int64_t need = (units_per_launch + groups_per_block - 1) / groups_per_block;
         // Default concurrency: 4 workgroups of 4 wavefronts per CU (1024 workgroups, 16 k interactions in flight on
         // MI355X).  Measured on BASELINE config 2 the update rate saturates there (profiles/); more wavefronts only add
         // staleness.  All workgroups are resident, so they sweep the epoch's order together and the realised order stays
         // close to the sequential one.  Never keep more than 1/128 of an epoch in flight: every in-flight update reads
         // weights that are stale by up to that many steps, and Hogwild only tracks sequential SGD while that window is
         // a small fraction of the data (DESIGN.md "staleness").
-        int64_t cap = (int64_t)(g_sm_count > 0 ? g_sm_count : 256) * 4;
+        int64_t cap = (int64_t)(g_sm_count > 0 ? g_sm_count : 256) * 16 / waves_per_block;
         const int64_t window = (N / 128 + groups_per_block - 1) / groups_per_block;
         if (window < cap) cap = window;
+        // ... and keep conflicts sparse: with g interactions in flight an update meets ~2g/I concurrent updates of its two
+        // item rows and ~g/U of its user row.  Ranking quality tracks the sequential reference while g <= min(U, I) / 3
+        // and collapses beyond ~1 (measured on the MovieLens-1M-shaped surrogate, profiles/r01_notes.md).
+        const int64_t sparse = ((int64_t)(cfg->n_users < cfg->n_items ? cfg->n_users : cfg->n_items) / 3 + groups_per_block - 1) / groups_per_block;
+        if (sparse < cap) cap = sparse;
+        if (cap < 1) cap = 1;
         if (cfg->n_workgroups > 0) cap = cfg->n_workgroups;
         grid = (int)(need < cap ? need : cap);
         if (grid < 1 || single_group) grid = 1;
+        // feature tables live in per-workgroup LDS replicas that are merged (averaged) at the end of every launch: give each
+        // replica >= ~1024 interactions per window, and split the epoch into up to 16 windows so the merges stay frequent
+        if (use_segments && feat && !single_group && cfg->rows_per_launch <= 0) {
+            int64_t windows = N / ((int64_t)grid * 1024);
+            if (windows > 16) windows = 16;
+            if (windows > 1) units_per_launch = (units + windows - 1) / windows;
+        }
     }
     const int launches = (int)((units + units_per_launch - 1) / units_per_launch);
 
@@ -389,8 +411,10 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     //      scale = min(1, M / n) = min(1, cap / count)
     const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
     const bool damp = !serial && !single_group && damp_m > 0.0f && N > 0;
-    const long long in_flight = single_group ? 1 : (long long)grid * 4 * groups_per_wave;
+    const long long in_flight = single_group ? 1 : (long long)grid * waves_per_block * groups_per_wave;
     const float damp_cap = damp ? damp_m * (float)N / (float)in_flight : 0.0f;
+    // a user's in-flight SEGMENT publishes its accumulated steps only when it ends: count a concurrent segment as its length
+    const float avg_seg = use_segments && n_segments > 0 ? (float)N / (float)n_segments : 1.0f;
     if (damp && build_plan) {
         RFM_HIP(hipMemsetAsync(ws.pos_scale, 0, sizeof(float) * (size_t)cfg->n_items, stream));
         item_count_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, (long long)N, (int *)ws.pos_scale);
@@ -419,6 +443,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.sw_csr = ws.sw_csr; a.seg_desc = ws.seg_desc; a.n_segments = n_segments;
         a.seg_bits = rfm_perm_bits((uint32_t)(n_segments > 0 ? n_segments : 1));
         a.single_group = single_group ? 1 : 0;
+        a.feat_snapshot = ws.feat_snapshot;
+        a.feat_merge = 1.0f / (float)grid;
         // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
         a.eta = cfg->learning_schedule == RFM_SCHEDULE_CONSTANT
                     ? cfg->learning_rate
@@ -427,16 +453,28 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.reg_b = 2.0f * cfg->beta;       // :172
         a.update_mode = cfg->debug_update_mode;
         a.pos_scale = damp ? ws.pos_scale : nullptr;
-        a.user_cap = damp ? damp_cap : INFINITY;
+        a.user_cap = damp ? damp_cap / avg_seg : INFINITY;
         // the dense feature tables are touched by EVERY in-flight row and shrink by 2*beta*eta per touch: keep the summed
         // stale shrink of one in-flight window below 1/2 as well
         a.feat_scale = damp ? fminf(1.0f, fminf(damp_m / (float)in_flight,
                                                 0.5f / ((float)in_flight * a.eta * fmaxf(a.reg_b, 1e-6f)))) : 1.0f;
 
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e], stream));
-        for (int64_t p0 = 0; p0 < units; p0 += units_per_launch) {
+        // merge rule of the LDS feature replicas: a replica trains on ~rows_per_window / workgroups interactions; if that is
+        // several times the tables' memory 1 / (2 * beta * eta), take one replica (rotating), else average them
+        const double rows_per_replica = (double)N / (double)launches / (double)(grid > 0 ? grid : 1);
+        const bool select_replica = rows_per_replica * (double)a.eta * (double)a.reg_b >= 4.0;
+        int window = 0;
+        for (int64_t p0 = 0; p0 < units; p0 += units_per_launch, ++window) {
+            a.feat_select_wg = (use_segments && feat && select_replica) ? (int)((e * launches + window) % grid) : -1;
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < units ? p0 + units_per_launch : units;
+            if (use_segments && feat) {      // the replicas start from, and are merged against, the tables as of now
+                const size_t nu = (size_t)cfg->n_user_features * cfg->n_factors, ni = (size_t)cfg->n_item_features * cfg->n_factors;
+                RFM_HIP(hipMemcpyAsync(ws.feat_snapshot, b->v_uf, sizeof(float) * nu, hipMemcpyDeviceToDevice, stream));
+                RFM_HIP(hipMemcpyAsync(ws.feat_snapshot + nu, b->v_if, sizeof(float) * ni, hipMemcpyDeviceToDevice, stream));
+                RFM_HIP(hipMemcpyAsync(ws.feat_snapshot + nu + ni, b->w_if, sizeof(float) * cfg->n_item_features, hipMemcpyDeviceToDevice, stream));
+            }
             launch(a, grid, stream);
         }
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));
@@ -502,7 +540,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->epochs_done = epochs_done;
         rep->nonfinite_array = bad_array;
         rep->launches_per_epoch = launches;
-        rep->waves_per_launch = single_group ? 1 : grid * (serial ? 1 : 4);
+        rep->waves_per_launch = single_group ? 1 : grid * waves_per_block;
         rep->plan_token = serial || b->perms ? 0 : (use_segments ? n_segments : kRowsPlan);
     }
     if (timing)

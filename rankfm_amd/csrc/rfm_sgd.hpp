@@ -67,6 +67,16 @@ struct SgdArgs {
     float feat_scale;                           // scale for the dense feature tables (every row touches them)
     int32_t update_mode;                        // experiments: 0 all atomics, 1 v_u plain RMW, 2 everything plain RMW
     int32_t single_group;                       // debug: only group 0 of wavefront 0 works (sequential Hogwild kernel)
+    // dense feature tables as per-workgroup LDS replicas (segments kernel with features): `feat_snapshot` holds
+    // [v_uf | v_if | w_if] as they were when the launch started; a workgroup loads it, trains on its replica and finally
+    // either adds (replica - snapshot) * feat_merge to the global tables (feat_merge = 1 / workgroups: the replicas'
+    // average) or -- feat_select_wg >= 0 -- that one workgroup stores its replica and the others are dropped.  Selection is
+    // the right merge while the tables forget faster than a window lasts (DESIGN.md "feature tables"): sequential SGD
+    // itself only remembers the last ~1/(2*beta*eta) rows, so any one replica is a fair sample of it, noise level included,
+    // whereas the average of K replicas has 1/sqrt(K) of the reference's noise and visibly smaller tables.
+    const float *__restrict__ feat_snapshot;
+    float feat_merge;
+    int32_t feat_select_wg;
 };
 
 constexpr float kMargin = 1.0f;                 // rankfm/_rankfm.pyx:149
@@ -143,13 +153,18 @@ __device__ __forceinline__ float log_sigmoid(float x) {
 //   VU_REGS  v_u lives in the caller's registers: the step updates them in place and does not touch v_u memory
 //   FRESH    item-row loads bypass L1
 // ---------------------------------------------------------------------------------------------
-template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH>
+//   LDSF     the dense feature tables (v_uf, v_if, w_if) are this workgroup's LDS replica: plain step size, LDS atomics
+template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false>
 struct RowStep {
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
     const int F;
+    float *t_v_uf, *t_v_if, *t_w_if; // feature tables: global memory, or the workgroup's LDS replica (LDSF)
 
-    __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_) : a(args), sub(sub_), F(args.n_factors) {}
+    __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_)
+        : a(args), sub(sub_), F(args.n_factors), t_v_uf(args.v_uf), t_v_if(args.v_if), t_w_if(args.w_if) {}
+    __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_, float *v_uf, float *v_if, float *w_if)
+        : a(args), sub(sub_), F(args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
 
     __device__ __forceinline__ int dword_f(int k) const { return sub + G * k; }
     __device__ __forceinline__ bool dword_ok(int k) const { return dword_f(k) < F; }
@@ -189,8 +204,8 @@ struct RowStep {
         if constexpr (FEAT) {
             if (a.has_if) {
                 const float *xi = a.x_if + (size_t)it * a.n_if;
-                project(xi, a.n_if, a.v_if, B);
-                for (int q = 0; q < a.n_if; ++q) scalar += xi[q] * a.w_if[q];
+                project(xi, a.n_if, t_v_if, B);
+                for (int q = 0; q < a.n_if; ++q) scalar += xi[q] * t_w_if[q];
             } else {
                 zero(B);
             }
@@ -228,7 +243,7 @@ struct RowStep {
         uint32_t attempt = 0;
         float A[KPL];
         if constexpr (FEAT) {
-            if (a.has_uf) project(a.x_uf + (size_t)u * a.n_uf, a.n_uf, a.v_uf, A);
+            if (a.has_uf) project(a.x_uf + (size_t)u * a.n_uf, a.n_uf, t_v_uf, A);
             else zero(A);
         }
 
@@ -263,7 +278,7 @@ struct RowStep {
         if constexpr (!SERIAL) {
             eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
             if (a.pos_scale) eta_i = eta * a.pos_scale[i];
-            eta_f = eta * a.feat_scale;
+            if constexpr (!LDSF) eta_f = eta * a.feat_scale;
         }
         const bool plain_items = !SERIAL && a.update_mode >= 2, plain_user = !SERIAL && a.update_mode >= 1;
 
@@ -280,8 +295,8 @@ struct RowStep {
             if (a.has_if) {
                 const float *xi = a.x_if + (size_t)i * a.n_if, *xj = a.x_if + (size_t)j * a.n_if;
                 for (int q = sub; q < a.n_if; q += G) {
-                    const float w = a.w_if[q];
-                    apply_f32<SERIAL>(a.w_if + q, w, eta_f * (g * (d_outer * (xi[q] - xj[q])) - reg_b * w));
+                    const float w = t_w_if[q];
+                    apply_f32<SERIAL>(t_w_if + q, w, eta_f * (g * (d_outer * (xi[q] - xj[q])) - reg_b * w));
                 }
             }
         }
@@ -317,7 +332,7 @@ struct RowStep {
                 for (int p = 0; p < a.n_uf; ++p) {
                     const float xp = xu[p];
                     if (xp == 0.0f) continue;
-                    float *trow = a.v_uf + (size_t)p * F;
+                    float *trow = t_v_uf + (size_t)p * F;
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
@@ -332,7 +347,7 @@ struct RowStep {
                 for (int q = 0; q < a.n_if; ++q) {
                     const float dx = xi[q] - xj[q];
                     if (dx == 0.0f) continue;
-                    float *trow = a.v_if + (size_t)q * F;
+                    float *trow = t_v_if + (size_t)q * F;
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
@@ -398,14 +413,24 @@ __global__ void __launch_bounds__(256) sgd_rows_kernel(const SgdArgs a) {
 //   [fetch segment + v_u] -> row, row, ... -> [write back v_u delta] -> next segment
 // so the four groups of a wavefront stay busy although their segments differ in length.
 // ---------------------------------------------------------------------------------------------
+// With features the workgroup is 1024 threads (16 wavefronts): the feature tables are per-WORKGROUP replicas, and fewer,
+// larger workgroups mean fewer replicas for the same number of interactions in flight.
 template <int G, int KPL, bool FEAT, bool FRESH>
-__global__ void __launch_bounds__(256) sgd_segments_kernel(const SgdArgs a) {
+__global__ void __launch_bounds__(FEAT ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
-    const RowStep<G, KPL, false, FEAT, true, FRESH> step(a, sub);
     const int F = a.n_factors;
+    // feature tables: this workgroup's replica in LDS (see SgdArgs::feat_snapshot)
+    extern __shared__ __attribute__((aligned(16))) float lds_tables[];
+    const int n_tab = FEAT ? (a.n_uf + a.n_if) * F + a.n_if : 0;
+    if constexpr (FEAT) {
+        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = a.feat_snapshot[k];
+        __syncthreads();
+    }
+    const RowStep<G, KPL, false, FEAT, true, FRESH, FEAT> step(a, sub, lds_tables, lds_tables + a.n_uf * F,
+                                                              lds_tables + (a.n_uf + a.n_if) * F);
 
     double ll_acc = 0.0;
     unsigned draw_acc = 0;
@@ -449,6 +474,20 @@ __global__ void __launch_bounds__(256) sgd_segments_kernel(const SgdArgs a) {
                 have = false;
                 sp += stride;
                 active = sp < a.pos_end;
+            }
+        }
+    }
+    if constexpr (FEAT) {
+        __syncthreads();
+        if (a.feat_select_wg < 0 || a.feat_select_wg == (int)blockIdx.x) {
+            for (int k = threadIdx.x; k < n_tab; k += blockDim.x) {
+                float *dst = k < a.n_uf * F ? a.v_uf + k : (k < (a.n_uf + a.n_if) * F ? a.v_if + (k - a.n_uf * F) : a.w_if + (k - (a.n_uf + a.n_if) * F));
+                if (a.feat_select_wg >= 0) {
+                    *dst = lds_tables[k];
+                } else {
+                    const float d = (lds_tables[k] - a.feat_snapshot[k]) * a.feat_merge;
+                    if (d != 0.0f) atomic_add_f32(dst, d);
+                }
             }
         }
     }

@@ -1,0 +1,66 @@
+"""GPU-box experiment: ranking-quality parity (hit_rate@10 and friends, factor norms) between the Hogwild engine and the
+sequential CPU oracle (the pinned restatement of the reference) on the planted MovieLens-1M-shaped surrogate, several seeds.
+BASELINE.json config 1: factors=20, loss='bpr', epochs=5.   (uses oracle/: tooling, not product)"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import pandas as pd
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc
+from rankfm_amd import EngineOptions, RankFM, evaluation, synthetic
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--users", type=int, default=6040)
+ap.add_argument("--items", type=int, default=3706)
+ap.add_argument("--factors", type=int, default=20)
+ap.add_argument("--loss", default="bpr")
+ap.add_argument("--max-samples", type=int, default=20)
+ap.add_argument("--epochs", type=int, default=5)
+ap.add_argument("--seeds", type=int, default=3)
+ap.add_argument("--tags", type=int, default=0)
+ap.add_argument("--schedule", default="constant")
+ap.add_argument("--workgroups", default="0")
+ap.add_argument("--dampings", default="0")
+a = ap.parse_args()
+
+rows = []
+for seed in range(a.seeds):
+    d = synthetic.make_planted(a.users, a.items, seed=seed, n_tags=a.tags)
+    train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
+    uf = itf = None
+    if a.tags:
+        uf = pd.concat([pd.DataFrame({"u": np.arange(a.users)}), pd.DataFrame(d["user_tags"])], axis=1)
+        itf = pd.concat([pd.DataFrame({"i": np.arange(a.items)}), pd.DataFrame(d["item_tags"])], axis=1)
+    res = {}
+    sides = ["oracle"] + ["gpu:%s:%s" % (w, m) for w in a.workgroups.split(",") for m in a.dampings.split(",")]
+    for side in sides:
+        wg, damp = (int(side.split(":")[1]), float(side.split(":")[2])) if side != "oracle" else (0, 0.0)
+        m = RankFM(factors=a.factors, loss=a.loss, max_samples=a.max_samples, learning_schedule=a.schedule,
+                   engine=EngineOptions(seed=100 + seed, n_workgroups=wg, damping=damp))
+        np.random.seed(seed)
+        t0 = time.time()
+        if side != "oracle":
+            m.fit(train, uf, itf, epochs=a.epochs)
+        else:
+            m._init_all(train, uf, itf, None)          # same initial weights (same numpy stream) as the GPU side
+            ms = 1 if a.loss == "bpr" else a.max_samples
+            orc.fit(m.interactions, m.sample_weight, m.user_items.offsets, m.user_items.items, m.x_uf, m.x_if, m.w_i, m.w_if,
+                    m.v_u, m.v_i, m.v_uf, m.v_if, m.alpha, m.beta, m.learning_rate, m.learning_schedule, m.learning_exponent,
+                    ms, a.epochs, perms=None, rng_mode=orc.RNG_COUNTER, seed=100 + seed, membership="binary")
+            m.is_fit = True
+        dt = time.time() - t0
+        res[side] = dict(hit=evaluation.hit_rate(m, test, k=10), mrr=evaluation.reciprocal_rank(m, test, k=10),
+                         prec=evaluation.precision(m, test, k=10), rec=evaluation.recall(m, test, k=10),
+                         nvu=np.linalg.norm(m.v_u), nvi=np.linalg.norm(m.v_i), nwi=np.linalg.norm(m.w_i), t=dt)
+    rows.append(res)
+    print("seed %d  n_train %d" % (seed, len(train)), {s: {k: round(float(v), 4) for k, v in r.items()} for s, r in res.items()}, flush=True)
+for side in [s for s in rows[0] if s != "oracle"]:
+    print("==", side)
+    for k in ("hit", "mrr", "prec", "rec", "nvu", "nvi", "nwi", "t"):
+        o = np.array([r["oracle"][k] for r in rows]); g = np.array([r[side][k] for r in rows])
+        print("%-5s oracle %.4f +- %.4f   gpu %.4f +- %.4f   diff %+.4f (%+.2f%%)" % (k, o.mean(), o.std(), g.mean(), g.std(), g.mean() - o.mean(),
+              100 * (g.mean() - o.mean()) / o.mean()))
