@@ -71,7 +71,8 @@ def cpu_baseline(pairs, csr, F, seconds_budget=25.0):
     t = run(n_rows)
     return dict(value=n_rows / t, unit="updates/s", cores=1, kind="port",
                 sample="%d randomly sampled rows of the same workload, 1 epoch, oracle/rfm_oracle.c (gcc -O2 -ffast-math, "
-                       "MT19937 + linear membership scan like the reference), %.1f s on 1 core of %d" % (n_rows, t, os.cpu_count() or 0))
+                       "MT19937 + linear membership scan like the reference; 1.19x the time of the reference's Cython _fit per tools/calibrate_cpu.py), "
+                       "%.1f s on 1 core of %d" % (n_rows, t, os.cpu_count() or 0))
 
 
 def main():
