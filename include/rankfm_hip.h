@@ -97,7 +97,8 @@ typedef struct rfm_fit_config {
     int32_t debug_update_mode;     /* experiments: 0 all atomics (default), 1 v_u plain stores, 2 everything plain stores */
     int32_t debug_shape;           /* experiments: 1-based index into the kernel shape table, 0 = automatic */
     int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
-                                      bit 1: factor-row loads bypass the per-CU L1 */
+                                      bit 1: factor-row loads bypass the per-CU L1,
+                                      bit 2: no LDS accumulation of hot item rows */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
                                       scales) into the head of `workspace`; > 0: the value rfm_fit_report.plan_token returned
                                       by an earlier call on the SAME workspace, interactions, geometry and damping -- the

@@ -7,8 +7,10 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -159,6 +161,8 @@ struct Workspace {
     float *pos_scale;             // [I]     persistent across calls (plan_is_cached)
     float *sw_csr;                // [N]     persistent
     int4 *seg_desc;               // [<= U + N / kSegmentRows]  persistent
+    int32_t *hot_item;            // [kMaxHot] persistent
+    int32_t *hot_period;          // [kMaxHot] persistent
     size_t volatile_offset;       // everything from here on is zeroed at the start of every call
     double *ll;                   // [epochs]
     unsigned long long *draws;    // [epochs]
@@ -173,6 +177,8 @@ struct Workspace {
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
+constexpr int kMaxHot = 64;                      // hot-row accumulator slots per workgroup (LDS: kMaxHot * (F + 2) floats)
+
 static size_t max_segments(int64_t n_rows, int n_users) { return (size_t)n_users + (size_t)(n_rows / kSegmentRows) + 1; }
 
 static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_feat_tab) {
@@ -182,6 +188,8 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.pos_scale = (float *)(p + o);              o += align_up(sizeof(float) * (size_t)n_items);
     w.sw_csr = (float *)(p + o);                 o += align_up(sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1));
     w.seg_desc = (int4 *)(p + o);                o += align_up(sizeof(int4) * max_segments(n_rows, n_users));
+    w.hot_item = (int32_t *)(p + o);             o += align_up(sizeof(int32_t) * kMaxHot);
+    w.hot_period = (int32_t *)(p + o);           o += align_up(sizeof(int32_t) * kMaxHot);
     w.volatile_offset = o;
     w.ll = (double *)(p + o);                    o += align_up(sizeof(double) * epochs);
     w.draws = (unsigned long long *)(p + o);     o += align_up(sizeof(unsigned long long) * epochs);
@@ -322,7 +330,10 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // ---- plan, part 1 (segments kernel): user segments.  A user of degree d is cut into ceil(d / 32) near-equal runs of
     //      consecutive CSR positions; descriptors {user, first position, length} are built on the host from the offsets.
     //      The plan lives in the persistent head of the workspace; `plan_token` (= segment count) says it is still valid.
-    int64_t n_segments = (cfg->plan_token > 0 && cfg->plan_token != kRowsPlan) ? cfg->plan_token : 0;
+    // plan_token = segment count | hot-slot count << 40
+    const bool have_plan = cfg->plan_token > 0 && cfg->plan_token != kRowsPlan;
+    int64_t n_segments = have_plan ? (cfg->plan_token & (((int64_t)1 << 40) - 1)) : 0;
+    int n_hot = have_plan ? (int)(cfg->plan_token >> 40) : 0;
     const bool build_plan = !serial && cfg->plan_token <= 0;
     if (use_segments && build_plan) {
         std::vector<int64_t> off((size_t)cfg->n_users + 1);
@@ -363,13 +374,40 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         }
     }
     const bool single_group = use_segments && (cfg->debug_flags & 1) != 0, fresh = (cfg->debug_flags & 2) != 0;
-    const sgd_launch_fn launch = use_segments ? shape->table()[4 + (feat ? 1 : 0) + (fresh ? 2 : 0)]
-                                              : shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
+    const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
+    const bool damp = !serial && !single_group && damp_m > 0.0f && N > 0;
+
+    // ---- plan, part 2: item popularity (positive occurrences per item), needed by the damping and by the hot-row choice
+    std::vector<int> item_count;
+    if (damp && build_plan) {
+        item_count.resize((size_t)cfg->n_items);
+        RFM_HIP(hipMemsetAsync(ws.pos_scale, 0, sizeof(float) * (size_t)cfg->n_items, stream));
+        item_count_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, (long long)N, (int *)ws.pos_scale);
+        RFM_HIP(hipMemcpyAsync(item_count.data(), ws.pos_scale, sizeof(int) * item_count.size(), hipMemcpyDeviceToHost, stream));
+        RFM_HIP(hipStreamSynchronize(stream));
+    }
+    // Hot rows: items that >= kHotMin in-flight updates would touch at once (estimated with the default geometry).  Their
+    // atomics serialise on one or two cache lines -- on BASELINE config 2 the ten hottest items cost half the epoch -- so
+    // the HOT kernel accumulates them per workgroup in LDS.  (bit 2 of debug_flags switches this off.)
+    std::vector<int> hot_order;
+    if (damp && build_plan && use_segments && !feat && !(cfg->debug_flags & 4) && cfg->n_factors <= 126) {
+        const double g0 = (double)(g_sm_count > 0 ? g_sm_count : 256) * 16.0 * (64 / shape->group);
+        const double kHotMin = 16.0;
+        for (int i = 0; i < cfg->n_items; ++i)
+            if ((double)item_count[i] * g0 / (double)N >= kHotMin) hot_order.push_back(i);
+        std::sort(hot_order.begin(), hot_order.end(), [&](int x, int y) { return item_count[x] > item_count[y] || (item_count[x] == item_count[y] && x < y); });
+        if ((int)hot_order.size() > kMaxHot) hot_order.resize(kMaxHot);
+        n_hot = (int)hot_order.size();
+    }
+    const bool use_hot = use_segments && !feat && !single_group && n_hot > 0;
+    const sgd_launch_fn launch = use_hot ? shape->table()[8 + (fresh ? 1 : 0)]
+                                 : use_segments ? shape->table()[4 + (feat ? 1 : 0) + (fresh ? 2 : 0)]
+                                                : shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
 
     // ---- launch geometry.  unit of work = one interaction (rows kernel) or one user segment (segments kernel)
     const int64_t units = use_segments ? n_segments : N;
     const int groups_per_wave = serial ? 1 : 64 / shape->group;
-    const int waves_per_block = serial ? 1 : (use_segments && feat ? 16 : 4);      // see sgd_segments_kernel
+    const int waves_per_block = serial ? 1 : (use_segments && (feat || use_hot) ? 16 : 4);      // see sgd_segments_kernel
     int grid = 1;
     int64_t units_per_launch = units > 0 ? units : 1;
     if (!serial) {
@@ -407,18 +445,36 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     }
     const int launches = (int)((units + units_per_launch - 1) / units_per_launch);
 
-    // ---- plan, part 2: Hogwild damping.  n(row) = in-flight interactions x the row's share of the data;
-    //      scale = min(1, M / n) = min(1, cap / count)
-    const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
-    const bool damp = !serial && !single_group && damp_m > 0.0f && N > 0;
+    // ---- plan, part 3: Hogwild damping.  n(row) = interactions in flight x the row's share of the data (+ what the other
+    //      workgroups hold unpublished for a hot row); scale = min(1, M / n)
     const long long in_flight = single_group ? 1 : (long long)grid * waves_per_block * groups_per_wave;
     const float damp_cap = damp ? damp_m * (float)N / (float)in_flight : 0.0f;
     // a user's in-flight SEGMENT publishes its accumulated steps only when it ends: count a concurrent segment as its length
     const float avg_seg = use_segments && n_segments > 0 ? (float)N / (float)n_segments : 1.0f;
     if (damp && build_plan) {
-        RFM_HIP(hipMemsetAsync(ws.pos_scale, 0, sizeof(float) * (size_t)cfg->n_items, stream));
-        item_count_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, (long long)N, (int *)ws.pos_scale);
-        item_scale_kernel<<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>((int *)ws.pos_scale, cfg->n_items, damp_cap);
+        std::vector<float> scale((size_t)cfg->n_items);
+        for (int i = 0; i < cfg->n_items; ++i) {
+            const double n = (double)in_flight * (double)item_count[i] / (double)N;
+            scale[i] = n > damp_m ? (float)(damp_m / n) : 1.0f;
+        }
+        std::vector<int32_t> h_item(kMaxHot, 0), h_period(kMaxHot, 1);
+        const double hot_pubs = getenv("RFM_HOT_PUBS") ? atof(getenv("RFM_HOT_PUBS")) : 24.0;   // experiment knob
+        for (int s = 0; s < (use_hot ? n_hot : 0); ++s) {
+            const int i = hot_order[s];
+            // publish about 24 times per epoch and workgroup: ~4 % of the row's updates are pending chip-wide at any time
+            int period = (int)((double)item_count[i] / ((double)grid * hot_pubs) + 0.5);
+            if (period < 1) period = 1;
+            if (period > 64) period = 64;
+            const double n = (double)in_flight * (double)item_count[i] / (double)N + 0.5 * (double)grid * (double)period;
+            const float sc = n > damp_m ? (float)(damp_m / n) : 1.0f;
+            scale[i] = sc + 2.0f * (float)(s + 1);              // slot encoded above the scale (see SgdArgs::hot_item)
+            h_item[s] = i;
+            h_period[s] = period;
+        }
+        RFM_HIP(hipMemcpyAsync(ws.pos_scale, scale.data(), sizeof(float) * scale.size(), hipMemcpyHostToDevice, stream));
+        RFM_HIP(hipMemcpyAsync(ws.hot_item, h_item.data(), sizeof(int32_t) * kMaxHot, hipMemcpyHostToDevice, stream));
+        RFM_HIP(hipMemcpyAsync(ws.hot_period, h_period.data(), sizeof(int32_t) * kMaxHot, hipMemcpyHostToDevice, stream));
+        RFM_HIP(hipStreamSynchronize(stream));              // pageable host vectors
     }
 
     std::vector<hipEvent_t> ev((size_t)2 * E, nullptr);
@@ -443,6 +499,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.sw_csr = ws.sw_csr; a.seg_desc = ws.seg_desc; a.n_segments = n_segments;
         a.seg_bits = rfm_perm_bits((uint32_t)(n_segments > 0 ? n_segments : 1));
         a.single_group = single_group ? 1 : 0;
+        a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
         a.feat_snapshot = ws.feat_snapshot;
         a.feat_merge = 1.0f / (float)grid;
         // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
@@ -541,7 +598,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->nonfinite_array = bad_array;
         rep->launches_per_epoch = launches;
         rep->waves_per_launch = single_group ? 1 : grid * waves_per_block;
-        rep->plan_token = serial || b->perms ? 0 : (use_segments ? n_segments : kRowsPlan);
+        rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40)) : kRowsPlan);
     }
     if (timing)
         for (auto &e : ev) hipEventDestroy(e);

@@ -77,6 +77,12 @@ struct SgdArgs {
     const float *__restrict__ feat_snapshot;
     float feat_merge;
     int32_t feat_select_wg;
+    // hot positive items (segments kernel, HOT instantiation): pos_scale[i] >= 2 encodes slot = int(v / 2) - 1 and
+    // scale = v - 2 (slot + 1).  A workgroup accumulates its updates of slot s in LDS and publishes them with one set of
+    // atomics every hot_period[s] touches (DESIGN.md "hot rows").
+    const int32_t *__restrict__ hot_item;       // [n_hot] item index of each slot
+    const int32_t *__restrict__ hot_period;     // [n_hot] touches per workgroup between publications
+    int32_t n_hot;
 };
 
 constexpr float kMargin = 1.0f;                 // rankfm/_rankfm.pyx:149
@@ -154,12 +160,16 @@ __device__ __forceinline__ float log_sigmoid(float x) {
 //   FRESH    item-row loads bypass L1
 // ---------------------------------------------------------------------------------------------
 //   LDSF     the dense feature tables (v_uf, v_if, w_if) are this workgroup's LDS replica: plain step size, LDS atomics
-template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false>
+//   HOT      updates of hot positive items are accumulated in the workgroup's LDS and published every few touches
+template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false>
 struct RowStep {
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
     const int F;
     float *t_v_uf, *t_v_if, *t_w_if; // feature tables: global memory, or the workgroup's LDS replica (LDSF)
+    float *hot_acc = nullptr;        // LDS [n_hot, F] pending factor deltas,  [n_hot] pending bias deltas, [n_hot] touch counters
+    float *hot_accw = nullptr;
+    int *hot_cnt = nullptr;
 
     __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_)
         : a(args), sub(sub_), F(args.n_factors), t_v_uf(args.v_uf), t_v_if(args.v_if), t_w_if(args.w_if) {}
@@ -197,9 +207,17 @@ struct RowStep {
     //   w_i[it] + sum_q x_if[it,q] w_if[q] + sum_f [ (vu_f + A_f) * vi_f + B_f(it) * vu_f ]
     // A = x_uf[u] . v_uf  (user-feature projection), B(it) = x_if[it] . v_if  (item-feature projection)
     __device__ __forceinline__ float utility(const float (&vu)[KPL], const float (&A)[KPL], int32_t it, float (&vi)[KPL],
-                                             float (&B)[KPL], float &wi) const {
+                                             float (&B)[KPL], float &wi, int slot = -1) const {
         load_row<FRESH>(a.v_i + (size_t)it * F, vi);
         wi = load_f32<FRESH>(a.w_i + it);
+        if constexpr (HOT) {
+            if (slot >= 0) {      // the workgroup's own pending updates of a hot row are part of its view of the row
+#pragma unroll
+                for (int k = 0; k < KPL; ++k)
+                    if (dword_ok(k)) vi[k] += hot_acc[slot * F + dword_f(k)];
+                wi += hot_accw[slot];
+            }
+        }
         float part = 0.0f, scalar = 0.0f;
         if constexpr (FEAT) {
             if (a.has_if) {
@@ -247,8 +265,21 @@ struct RowStep {
             else zero(A);
         }
 
+        int slot = -1;
+        float pos_scale_i = 1.0f;
+        if constexpr (!SERIAL) {
+            if (a.pos_scale) {
+                pos_scale_i = a.pos_scale[i];
+                if constexpr (HOT) {
+                    if (pos_scale_i >= 2.0f) {
+                        slot = (int)(pos_scale_i * 0.5f) - 1;
+                        pos_scale_i -= 2.0f * (float)(slot + 1);
+                    }
+                }
+            }
+        }
         float vi[KPL], Bi[KPL], wi;
-        const float ut_ui = utility(vu, A, i, vi, Bi, wi);               // :239
+        const float ut_ui = utility(vu, A, i, vi, Bi, wi, slot);         // :239
 
         // WARP sampling loop (:244-264); BPR is max_samples == 1
         float vj[KPL], Bj[KPL], wj = 0.0f;
@@ -277,16 +308,19 @@ struct RowStep {
         float eta_u = eta, eta_i = eta, eta_f = eta;
         if constexpr (!SERIAL) {
             eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
-            if (a.pos_scale) eta_i = eta * a.pos_scale[i];
+            eta_i = eta * pos_scale_i;
             if constexpr (!LDSF) eta_f = eta * a.feat_scale;
         }
-        const bool plain_items = !SERIAL && a.update_mode >= 2, plain_user = !SERIAL && a.update_mode >= 1;
+        const bool plain_items = !SERIAL && a.update_mode == 2, plain_user = !SERIAL && (a.update_mode == 1 || a.update_mode == 2);
+        // experiment (update_mode 3): drop the positive item's atomics when the item is hot -- measures what they cost
+        const bool skip_pos = !SERIAL && a.update_mode == 3 && pos_scale_i < 1.0f;
 
         // item biases (:279-280) -- one lane per group
         if (sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
-            apply_f32<SERIAL>(a.w_i + i, wi, dwi, plain_items);
+            if (HOT && slot >= 0) atomicAdd(hot_accw + slot, dwi);
+            else if (!skip_pos) apply_f32<SERIAL>(a.w_i + i, wi, dwi, plain_items);
             apply_f32<SERIAL>(a.w_i + j, wj, dwj, plain_items);
         }
 
@@ -316,13 +350,34 @@ struct RowStep {
             if (dword_ok(k)) {
                 const int f = dword_f(k);
                 if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u, plain_user);
-                apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i, plain_items);
+                if (HOT && slot >= 0) atomicAdd(hot_acc + slot * F + f, d_i);
+                else if (!skip_pos) apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i, plain_items);
                 apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
             }
         }
         if constexpr (VU_REGS) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) vu[k] = nvu[k];
+        }
+        if constexpr (HOT) {
+            if (slot >= 0) {
+                // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it
+                int c = 0;
+                if (sub == 0) c = atomicAdd(hot_cnt + slot, 1) + 1;
+                c = __shfl(c, (threadIdx.x & 63) - sub);
+                if (c % a.hot_period[slot] == 0) {
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k) {
+                        if (!dword_ok(k)) continue;
+                        const float d = atomicExch(hot_acc + slot * F + dword_f(k), 0.0f);
+                        if (d != 0.0f) atomic_add_f32(a.v_i + (size_t)i * F + dword_f(k), d);
+                    }
+                    if (sub == 0) {
+                        const float d = atomicExch(hot_accw + slot, 0.0f);
+                        if (d != 0.0f) atomic_add_f32(a.w_i + i, d);
+                    }
+                }
+            }
         }
 
         if constexpr (FEAT) {
@@ -415,8 +470,10 @@ __global__ void __launch_bounds__(256) sgd_rows_kernel(const SgdArgs a) {
 // ---------------------------------------------------------------------------------------------
 // With features the workgroup is 1024 threads (16 wavefronts): the feature tables are per-WORKGROUP replicas, and fewer,
 // larger workgroups mean fewer replicas for the same number of interactions in flight.
-template <int G, int KPL, bool FEAT, bool FRESH>
-__global__ void __launch_bounds__(FEAT ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
+// The HOT instantiation (no features) also uses 1024 threads: the hot-row accumulators are per workgroup, and fewer,
+// larger workgroups combine more touches per publication at the same amount of unpublished work.
+template <int G, int KPL, bool FEAT, bool FRESH, bool HOT = false>
+__global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -429,8 +486,17 @@ __global__ void __launch_bounds__(FEAT ? 1024 : 256) sgd_segments_kernel(const S
         for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = a.feat_snapshot[k];
         __syncthreads();
     }
-    const RowStep<G, KPL, false, FEAT, true, FRESH, FEAT> step(a, sub, lds_tables, lds_tables + a.n_uf * F,
-                                                              lds_tables + (a.n_uf + a.n_if) * F);
+    RowStep<G, KPL, false, FEAT, true, FRESH, FEAT, HOT> step(a, sub, lds_tables, lds_tables + a.n_uf * F,
+                                                             lds_tables + (a.n_uf + a.n_if) * F);
+    if constexpr (HOT) {
+        // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] touch counters
+        const int n_acc = a.n_hot * (F + 2);
+        for (int k = threadIdx.x; k < n_acc; k += blockDim.x) lds_tables[k] = 0.0f;
+        __syncthreads();
+        step.hot_acc = lds_tables;
+        step.hot_accw = lds_tables + a.n_hot * F;
+        step.hot_cnt = reinterpret_cast<int *>(lds_tables + a.n_hot * (F + 1));
+    }
 
     double ll_acc = 0.0;
     unsigned draw_acc = 0;
@@ -477,6 +543,17 @@ __global__ void __launch_bounds__(FEAT ? 1024 : 256) sgd_segments_kernel(const S
             }
         }
     }
+    if constexpr (HOT) {          // publish whatever is still pending
+        __syncthreads();
+        for (int k = threadIdx.x; k < a.n_hot * F; k += blockDim.x) {
+            const float d = lds_tables[k];
+            if (d != 0.0f) atomic_add_f32(a.v_i + (size_t)a.hot_item[k / F] * F + (k % F), d);
+        }
+        for (int k = threadIdx.x; k < a.n_hot; k += blockDim.x) {
+            const float d = lds_tables[a.n_hot * F + k];
+            if (d != 0.0f) atomic_add_f32(a.w_i + a.hot_item[k], d);
+        }
+    }
     if constexpr (FEAT) {
         __syncthreads();
         if (a.feat_select_wg < 0 || a.feat_select_wg == (int)blockIdx.x) {
@@ -495,7 +572,7 @@ __global__ void __launch_bounds__(FEAT ? 1024 : 256) sgd_segments_kernel(const S
 }
 
 // host-side launcher table (rfm_sgd_inst_*.hip): [0..3] rows kernel {hogwild, hogwild+feat, serial, serial+feat},
-// [4..7] segments kernel {plain, feat, fresh, fresh+feat}
+// [4..7] segments kernel {plain, feat, fresh, fresh+feat}, [8..9] segments kernel with hot-row accumulators {plain, fresh}
 typedef void (*sgd_launch_fn)(const SgdArgs &, int grid, hipStream_t);
 
 }  // namespace rfm

@@ -28,6 +28,7 @@ ap.add_argument("--workgroups", default="0")
 ap.add_argument("--rows-per-launch", default="0")
 ap.add_argument("--sigma", type=float, default=0.1)
 ap.add_argument("--no-oracle", action="store_true")
+ap.add_argument("--debug-flags", default="0")
 a = ap.parse_args()
 U, I, N, F = a.users, a.items, a.rows, a.factors
 pairs, csr = synthetic.make_interactions(U, I, N, seed=0, zipf_s=a.zipf)
@@ -49,12 +50,12 @@ if not a.no_oracle:
     print("oracle %.1fs ll/N %s  " % (time.time() - t0, out["ll"] / N) + " ".join("|%s| %.3f" % (k, np.linalg.norm(o[k])) for k in NAMES), flush=True)
 for wg in [int(x) for x in a.workgroups.split(",")]:
     for rpl in [int(x) for x in a.rows_per_launch.split(",")]:
-        for m in [float(x) for x in a.dampings.split(",")]:
+        for m, fl in [(float(x), int(y)) for x in a.dampings.split(",") for y in a.debug_flags.split(",")]:
             sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=a.max_samples, seed=1492,
-                                 hogwild_damping=m, n_workgroups=wg, rows_per_launch=rpl)
+                                 hogwild_damping=m, n_workgroups=wg, rows_per_launch=rpl, debug_flags=fl)
             rep = sess.run(epochs=a.epochs, raise_on_error=False)
             g = sess.weights_to_host()
-            line = "wg=%4d rpl=%8d M=%6.1f st=%d launches=%d ms %s ll/N %s" % (wg, rpl, m, rep["status"], rep["launches_per_epoch"],
+            line = "flags=%d " % fl + "wg=%4d rpl=%8d M=%6.1f st=%d launches=%d ms %s ll/N %s" % (wg, rpl, m, rep["status"], rep["launches_per_epoch"],
                                                                          np.round(rep["sgd_kernel_ms"], 2), np.round(rep["log_likelihood"] / N, 4))
             if o is not None:
                 line += "  ll-ratio %s  norm-ratio " % np.round(rep["log_likelihood"] / out["ll"], 4)
