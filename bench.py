@@ -105,10 +105,18 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: rankfm_amd has no CPU fallback")
+    # RFM_BENCH_SHARE_GPU=1 (functional testing only): all ranks share cuda:0 and talk over gloo, so the N > 1 code path
+    # can be exercised on a one-GPU box; the driver's scaling runs use one GPU per rank over RCCL ("nccl").
+    share_gpu = os.environ.get("RFM_BENCH_SHARE_GPU", "") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg = synthetic.CONFIGS[args.config]
     U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
@@ -182,7 +190,7 @@ def main():
                        "mean_draws_per_update": mean_draws, "final_mean_ll_per_update": ll_last / N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rfm::sgd_kernel", "kernel_ms_per_launch": k_ms,
+                         "kernel": "rfm::sgd_segments_kernel", "kernel_ms_per_launch": k_ms,
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

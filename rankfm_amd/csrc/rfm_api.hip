@@ -409,6 +409,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     const int groups_per_wave = serial ? 1 : 64 / shape->group;
     const int waves_per_block = serial ? 1 : (use_segments && (feat || use_hot) ? 16 : 4);      // see sgd_segments_kernel
     int grid = 1;
+    int64_t max_groups = 0;
     int64_t units_per_launch = units > 0 ? units : 1;
     if (!serial) {
         if (cfg->rows_per_launch > 0 && cfg->rows_per_launch < N) {
@@ -432,6 +433,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         const int64_t sparse = ((int64_t)(cfg->n_users < cfg->n_items ? cfg->n_users : cfg->n_items) / 3 + groups_per_block - 1) / groups_per_block;
         if (sparse < cap) cap = sparse;
         if (cap < 1) cap = 1;
+        // both limits are in interactions (row groups); below one workgroup's worth the kernel idles the surplus groups
+        max_groups = N / 128 < (int64_t)(cfg->n_users < cfg->n_items ? cfg->n_users : cfg->n_items) / 3
+                         ? N / 128 : (int64_t)(cfg->n_users < cfg->n_items ? cfg->n_users : cfg->n_items) / 3;
+        if (max_groups < 1) max_groups = 1;
+        if (cfg->n_workgroups > 0) max_groups = 0;          // explicit geometry: no cap
         if (cfg->n_workgroups > 0) cap = cfg->n_workgroups;
         grid = (int)(need < cap ? need : cap);
         if (grid < 1 || single_group) grid = 1;
@@ -447,7 +453,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
 
     // ---- plan, part 3: Hogwild damping.  n(row) = interactions in flight x the row's share of the data (+ what the other
     //      workgroups hold unpublished for a hot row); scale = min(1, M / n)
-    const long long in_flight = single_group ? 1 : (long long)grid * waves_per_block * groups_per_wave;
+    long long in_flight = single_group ? 1 : (long long)grid * waves_per_block * groups_per_wave;
+    if (!single_group && max_groups > 0 && max_groups < in_flight) in_flight = max_groups;
     const float damp_cap = damp ? damp_m * (float)N / (float)in_flight : 0.0f;
     // a user's in-flight SEGMENT publishes its accumulated steps only when it ends: count a concurrent segment as its length
     const float avg_seg = use_segments && n_segments > 0 ? (float)N / (float)n_segments : 1.0f;
@@ -499,6 +506,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.sw_csr = ws.sw_csr; a.seg_desc = ws.seg_desc; a.n_segments = n_segments;
         a.seg_bits = rfm_perm_bits((uint32_t)(n_segments > 0 ? n_segments : 1));
         a.single_group = single_group ? 1 : 0;
+        a.max_groups = max_groups;
         a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
         a.feat_snapshot = ws.feat_snapshot;
         a.feat_merge = 1.0f / (float)grid;

@@ -67,6 +67,7 @@ struct SgdArgs {
     float feat_scale;                           // scale for the dense feature tables (every row touches them)
     int32_t update_mode;                        // experiments: 0 all atomics, 1 v_u plain RMW, 2 everything plain RMW
     int32_t single_group;                       // debug: only group 0 of wavefront 0 works (sequential Hogwild kernel)
+    int64_t max_groups;                         // row groups allowed to work (the concurrency cap can be below one workgroup)
     // dense feature tables as per-workgroup LDS replicas (segments kernel with features): `feat_snapshot` holds
     // [v_uf | v_if | w_if] as they were when the launch started; a workgroup loads it, trains on its replica and finally
     // either adds (replica - snapshot) * feat_merge to the global tables (feat_merge = 1 / workgroups: the replicas'
@@ -438,14 +439,17 @@ __global__ void __launch_bounds__(256) sgd_rows_kernel(const SgdArgs a) {
     const int grp = lane / G, sub = lane % G;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int64_t n_groups = n_waves * RPW;                                        // groups that work (concurrency cap)
+    if (!SERIAL && a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
+    const int64_t group = SERIAL ? 0 : wave * RPW + grp;
     const RowStep<G, KPL, SERIAL, FEAT, false, false> step(a, sub);
     const int F = a.n_factors;
 
     double ll_acc = 0.0;
     unsigned draw_acc = 0;
-    for (int64_t pos0 = a.pos_begin + wave * RPW; pos0 < a.pos_end; pos0 += n_waves * RPW) {
-        const int64_t pos = pos0 + (SERIAL ? 0 : grp);
-        const bool active = (pos < a.pos_end) && (!SERIAL || grp == 0);
+    const bool works = SERIAL ? (grp == 0) : (group < n_groups);
+    for (int64_t pos = a.pos_begin + group; __any(works && pos < a.pos_end); pos += n_groups) {
+        const bool active = works && pos < a.pos_end;
         if (active) {
             const int64_t row = a.perm ? (int64_t)a.perm[pos]
                                        : (int64_t)rfm_perm((uint32_t)pos, (uint32_t)a.n_rows, a.perm_bits, a.epoch_key);
@@ -477,7 +481,8 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
+    int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
+    if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
     const int F = a.n_factors;
     // feature tables: this workgroup's replica in LDS (see SgdArgs::feat_snapshot)
     extern __shared__ __attribute__((aligned(16))) float lds_tables[];
@@ -502,7 +507,7 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
     unsigned draw_acc = 0;
     int64_t sp = a.pos_begin + (a.single_group ? 0 : group);      // position in the epoch's segment order
     const int64_t stride = a.single_group ? 1 : n_groups;
-    bool active = sp < a.pos_end && (!a.single_group || group == 0);
+    bool active = sp < a.pos_end && (a.single_group ? group == 0 : group < n_groups);
     bool have = false;
     int32_t u = 0, begin = 0, len = 0, t = 0, len_bits = 0;
     uint32_t seg_key = 0;

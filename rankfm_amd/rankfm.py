@@ -259,6 +259,54 @@ class RankFM():
         else:
             raise ValueError("param [cold_start] must be set to either 'nan' or 'drop'")
 
+    # ------------------------------------------------------------------ persistence
+
+    _WEIGHTS = ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")
+
+    def save(self, path):
+        """write the fitted model to one .npz: hyper-parameters, id maps, the reference's weight layout (float32, C order),
+        features and the per-user item lists.  The reference has no serialisation; its models are plain attributes, and the
+        arrays written here are exactly those attributes, so they can be assigned onto a reference `RankFM` as well."""
+        assert self.is_fit, "you must fit the model prior to saving it"
+        hyper = dict(factors=self.factors, loss=self.loss, max_samples=self.max_samples, alpha=self.alpha, beta=self.beta,
+                     sigma=self.sigma, learning_rate=self.learning_rate, learning_schedule=self.learning_schedule,
+                     learning_exponent=self.learning_exponent)
+        def plain(ids):          # object arrays (mixed frames) hold either python ints or strings
+            if ids.dtype != object:
+                return ids
+            return ids.astype(np.int64) if all(isinstance(x, (int, np.integer)) for x in ids) else ids.astype("U")
+        ids_u, ids_i = plain(self.user_id.values), plain(self.item_id.values)
+        np.savez_compressed(
+            path, format=np.array("rankfm_amd/1"), hyper=np.array(repr(hyper)), epochs_trained=np.int64(self.epochs_trained),
+            user_id=ids_u, item_id=ids_i,
+            x_uf=self.x_uf, x_if=self.x_if, csr_offsets=self.user_items.offsets, csr_items=self.user_items.items,
+            **{k: getattr(self, k) for k in self._WEIGHTS})
+
+    @classmethod
+    def load(cls, path, engine=None):
+        """rebuild a fitted model from `save()` output; predict / recommend / fit_partial work on it immediately"""
+        import ast
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
+        assert str(z["format"]) == "rankfm_amd/1", "not a rankfm_amd model file"
+        m = cls(engine=engine, **ast.literal_eval(str(z["hyper"])))
+        m.user_id, m.item_id = pd.Series(z["user_id"]), pd.Series(z["item_id"])
+        if m.user_id.dtype.kind == "U":
+            m.user_id = m.user_id.astype(object)
+        if m.item_id.dtype.kind == "U":
+            m.item_id = m.item_id.astype(object)
+        m.index_to_user, m.index_to_item = m.user_id, m.item_id
+        m.user_to_index = pd.Series(data=m.index_to_user.index, index=m.index_to_user.values)
+        m.item_to_index = pd.Series(data=m.index_to_item.index, index=m.index_to_item.values)
+        m.user_idx = np.arange(len(m.user_id), dtype=np.int32)
+        m.item_idx = np.arange(len(m.item_id), dtype=np.int32)
+        m.x_uf, m.x_if = np.ascontiguousarray(z["x_uf"]), np.ascontiguousarray(z["x_if"])
+        m.user_items = UserItemsCSR(z["csr_offsets"], z["csr_items"])
+        for k in cls._WEIGHTS:
+            setattr(m, k, np.ascontiguousarray(z[k], dtype=np.float32))
+        m.epochs_trained = int(z["epochs_trained"])
+        m.is_fit = True
+        return m
+
     def similar_items(self, item_id, n_items=10):
         """most similar items wrt latent factor space representation (rankfm/rankfm.py:405-428)"""
         assert item_id in self.item_id.values, "you must select an [item_id] present in the training data"

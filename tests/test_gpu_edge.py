@@ -1,0 +1,124 @@
+"""Edge cases of the training path on the GPU, each against the sequential oracle in the engine's own order (tight
+tolerance, single-group mode of the production kernel) and -- where it makes sense -- as a full Hogwild run."""
+import numpy as np
+import pytest
+
+from conftest import WEIGHTS
+from test_gpu_parity import SERIAL_ATOL, SERIAL_RTOL, _oracle_in_engine_order
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(pairs, csr, sw, F, max_samples, epochs, seed, engine_kw, oracle, sigma=0.1, schedule="constant"):
+    from rankfm_amd import EngineOptions, synthetic
+    from rankfm_amd._rankfm import _fit
+    U, I = len(csr.offsets) - 1, int(max(pairs[:, 1].max() + 1, 2))
+    I = max(I, int(csr.items.max()) + 1 if len(csr.items) else I)
+    w0 = synthetic.init_weights(U, I, F, sigma=sigma, seed=seed)
+    x_uf, x_if = np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32)
+    g = {k: v.copy() for k, v in w0.items()}
+    rep = {}
+    _fit(pairs, sw, csr, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"], 0.01, 0.1, 0.1, schedule, 0.25,
+         max_samples, epochs, False, engine=EngineOptions(seed=seed, **engine_kw), report=rep)
+    o, out = _oracle_in_engine_order(oracle, (pairs, csr, sw, x_uf, x_if, None), w0, max_samples, epochs, seed, schedule=schedule)
+    return g, rep, o, out
+
+
+def _csr(pairs, U):
+    from rankfm_amd import UserItemsCSR
+    return UserItemsCSR.from_pairs(pairs[:, 0], pairs[:, 1], U)
+
+
+@pytest.mark.parametrize("F", [1, 2, 64])
+def test_tiny_problems(oracle, F):
+    """one interaction; two items only; every user a single row"""
+    for pairs, U in ((np.array([[0, 1]], np.int32), 1),
+                     (np.array([[0, 0], [1, 1], [2, 0]], np.int32), 3),
+                     (np.array([[u, (3 * u) % 7] for u in range(40)], np.int32), 40)):
+        csr = _csr(pairs, U)
+        sw = np.ones(len(pairs), np.float32)
+        for flags in (1, 0):          # sequential single group, then plain Hogwild (a handful of rows: still near-sequential)
+            g, rep, o, out = _run(pairs, csr, sw, F, 1, 3, 4, dict(debug_flags=flags), oracle)
+            # Hogwild on 1-40 rows: the concurrency cap min(U, I)/3 leaves one or two groups working -> still close
+            tol = dict(rtol=SERIAL_RTOL, atol=SERIAL_ATOL) if flags else dict(rtol=0.05, atol=5e-3)
+            for k in WEIGHTS:
+                np.testing.assert_allclose(g[k], o[k], err_msg="%s F=%d flags=%d" % (k, F, flags), **tol)
+
+
+def test_duplicate_interactions_and_zero_weights(oracle):
+    """the reference keeps repeated (user, item) rows -- each is a step (rankfm/rankfm.py:174 sorts, does not dedupe) -- and a
+    zero sample weight leaves only the L2 shrink"""
+    rng = np.random.default_rng(0)
+    base = np.stack([rng.integers(0, 30, 300), rng.integers(0, 50, 300)], 1).astype(np.int32)
+    pairs = np.concatenate([base, base[:120], base[:40]])            # up to three copies of a pair
+    sw = np.ones(len(pairs), np.float32)
+    sw[rng.random(len(pairs)) < 0.2] = 0.0
+    # copies of one pair must share a weight for a reproducible run: their CSR slots are interchangeable
+    key = pairs[:, 0].astype(np.int64) * 1000 + pairs[:, 1]
+    _, first = np.unique(key, return_index=True)
+    sw = sw[first][np.searchsorted(key[first], key)]
+    csr = _csr(pairs, 30)
+    assert len(csr.items) == len(pairs)
+    g, rep, o, out = _run(pairs, csr, sw, 16, 4, 2, 7, dict(debug_flags=1), oracle, sigma=0.4)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg=k)
+
+
+def test_heavy_user_spans_many_segments(oracle):
+    """one user holds 80 % of the catalogue (60+ segments, sampler rejects 4 draws in 5); the rest are light"""
+    rng = np.random.default_rng(1)
+    I, U = 400, 200
+    heavy = np.stack([np.zeros(320, np.int64), rng.permutation(I)[:320]], 1)
+    light = np.stack([rng.integers(1, U, 3000), rng.integers(0, I, 3000)], 1)
+    light = np.unique(light, axis=0)
+    pairs = np.concatenate([heavy, light]).astype(np.int32)
+    pairs = pairs[rng.permutation(len(pairs))]
+    csr = _csr(pairs, U)
+    sw = np.ones(len(pairs), np.float32)
+    g, rep, o, out = _run(pairs, csr, sw, 32, 1, 2, 11, dict(debug_flags=1), oracle)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg=k)
+    # full Hogwild on the same data stays finite and close (the heavy user's concurrent segments are damped)
+    g, rep, o, out = _run(pairs, csr, sw, 32, 1, 3, 11, {}, oracle)
+    assert all(np.isfinite(g[k]).all() for k in WEIGHTS)
+    np.testing.assert_allclose(rep["log_likelihood"], out["ll"], rtol=0.03)
+    assert abs(np.linalg.norm(g["v_i"]) - np.linalg.norm(o["v_i"])) < 0.03 * np.linalg.norm(o["v_i"])
+
+
+def test_invscaling_schedule_and_resumed_epochs(oracle):
+    """eta = lr / (epoch+1)^0.25 (rankfm/_rankfm.pyx:222-223); a second call continues the counter streams at epoch_begin"""
+    from rankfm_amd import synthetic
+    from rankfm_amd.engine import DeviceSession
+    pairs, csr = synthetic.make_interactions(150, 120, 4000, seed=5)
+    sw = np.ones(len(pairs), np.float32)
+    g, rep, o, out = _run(pairs, csr, sw, 20, 1, 3, 13, dict(debug_flags=1), oracle, schedule="invscaling")
+    for k in WEIGHTS:
+        np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg=k)
+    w0 = synthetic.init_weights(150, 120, 20, seed=13)
+    z_u, z_i = np.zeros((150, 1), np.float32), np.zeros((120, 1), np.float32)
+    one = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, learning_schedule="invscaling", seed=13, debug_flags=1)
+    one.run(epochs=3)
+    two = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, learning_schedule="invscaling", seed=13, debug_flags=1)
+    two.run(epochs=1)
+    two.run(epochs=2, epoch_begin=1)
+    a, b = one.weights_to_host(), two.weights_to_host()
+    for k in WEIGHTS:
+        assert np.array_equal(a[k], b[k]), k          # sequential single-group mode is bit-reproducible
+    for k in WEIGHTS:
+        np.testing.assert_allclose(a[k], g[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL)
+
+
+def test_max_samples_beyond_catalogue_is_reported_not_silent(oracle):
+    """(I-1) // sampled == 0 makes the reference's multiplier log(0) = -inf: weights go non-finite and
+    the epoch-end check must say so"""
+    from rankfm_amd import EngineOptions, UserItemsCSR, synthetic
+    from rankfm_amd._rankfm import _fit
+    pairs = np.array([[u, i] for u in range(3) for i in range(3)], np.int32)      # every user holds items 0..2
+    csr = UserItemsCSR.from_pairs(pairs[:, 0], pairs[:, 1], 3)
+    w = synthetic.init_weights(3, 5, 4, sigma=2.0, seed=1)
+    w["w_i"][:] = np.array([9, 9, 9, 0, 0], np.float32)          # positives far ahead of both negatives: no draw violates the margin
+    w["v_u"][:] = 0
+    z_u, z_i = np.zeros((3, 1), np.float32), np.zeros((5, 1), np.float32)
+    with pytest.raises(AssertionError, match="not finite"):
+        _fit(pairs, np.ones(len(pairs), np.float32), csr, z_u, z_i, w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"], 0.01, 0.1,
+             0.1, "constant", 0.25, 6, 1, False, engine=EngineOptions(mode="serial", seed=1))

@@ -169,3 +169,23 @@ def test_metric_definitions_against_per_user_set_logic():
     assert evaluation.recall(model, test, k) == pytest.approx(np.mean(rec))
     div = evaluation.diversity(model, test, k)
     assert list(div.columns) == ["item_id", "cnt_users", "pct_users"] and div["cnt_users"].sum() == k * len(users)
+
+
+def test_save_load_round_trip(tmp_path):
+    """§8 f4: the saved file holds the reference's weight layout + id maps; a loaded model is ready to score"""
+    m = RankFM(factors=3, loss="warp", max_samples=4, learning_schedule="invscaling")
+    np.random.seed(3)
+    toy = TOY.assign(user_id=TOY.user_id.map(lambda u: "u%d" % u))          # string ids survive the round trip
+    m._init_all(toy)
+    m.is_fit = True
+    m.epochs_trained = 7
+    m.save(tmp_path / "model")
+    r = RankFM.load(tmp_path / "model")
+    assert (r.factors, r.loss, r.max_samples, r.learning_schedule, r.epochs_trained, r.is_fit) == (3, "warp", 4, "invscaling", 7, True)
+    for k in WEIGHTS:
+        a, b = getattr(m, k), getattr(r, k)
+        assert b.dtype == np.float32 and b.flags.c_contiguous and np.array_equal(a, b)
+    assert list(r.user_id) == list(m.user_id) and list(r.item_id) == list(m.item_id)
+    assert r.user_to_index.loc["u30"] == m.user_to_index.loc["u30"]
+    assert np.array_equal(r.user_items.items, m.user_items.items) and np.array_equal(r.x_uf, m.x_uf)
+    assert r._lookup(np.array(["u20", "nobody"], dtype=object), "user").tolist() == [m.user_to_index.loc["u20"], -1]
