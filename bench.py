@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--damping", type=float, default=0.0, help="hogwild damping M (0 default, <0 off)")
     ap.add_argument("--debug-flags", type=int, default=0)
+    ap.add_argument("--factors", type=int, default=0, help="override the config's factor count (experiments)")
     ap.add_argument("--shape", type=int, default=0, help="experiment: 1-based index into the kernel shape table")
     args = ap.parse_args()
 
@@ -120,6 +121,8 @@ def main():
 
     cfg = synthetic.CONFIGS[args.config]
     U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
+    if args.factors > 0:
+        F = args.factors
     n_uf, n_if = cfg.get("n_user_features", 0), cfg.get("n_item_features", 0)
     # each rank generates ITS OWN user shard (different seed) over the shared item catalogue
     pairs, csr = synthetic.make_interactions(U, I, N, seed=1000 * rank, zipf_s=args.zipf)

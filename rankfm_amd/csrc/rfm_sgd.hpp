@@ -129,6 +129,41 @@ __device__ __forceinline__ bool is_member(const int32_t *__restrict__ items, int
     return false;
 }
 
+// The same predicate evaluated by all G lanes of a row group together: one or two memory round trips instead of
+// ~log2(degree) dependent ones.  Lists of up to 4G items are scanned outright (4 strided loads per lane, all in flight at
+// once); longer lists are first narrowed by G-ary search steps (G evenly spaced pivots per step).  Arguments are
+// group-uniform; every lane of the group must call it.
+template <int G>
+__device__ __forceinline__ unsigned group_ballot(bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if constexpr (G == 64) return (unsigned)(m != 0ull);          // only "any" is needed for a full-wave group (see callers)
+    else return (unsigned)((m >> (((threadIdx.x & 63) / G) * G)) & ((1ull << G) - 1ull));
+}
+
+template <int G>
+__device__ __forceinline__ bool is_member_group(const int32_t *__restrict__ items, int64_t lo, int64_t hi, int32_t item, int sub) {
+    while (hi - lo > 4 * G) {
+        const int64_t n = hi - lo, step = (n + G - 1) / G;
+        const int64_t p = lo + (int64_t)sub * step;
+        const int32_t v = p < hi ? items[p] : 0x7fffffff;
+        // lanes whose pivot is <= item form a prefix of the group (the list is sorted): its length picks the sub-range
+        int c;
+        if constexpr (G == 64) c = __popcll(__ballot(v <= item));
+        else c = __popc(group_ballot<G>(v <= item));
+        if (c == 0) return false;                                  // item below the first element
+        lo = lo + (int64_t)(c - 1) * step;
+        hi = lo + step < hi ? lo + step : hi;
+    }
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t idx = lo + sub + (int64_t)G * k;
+        if (idx < hi) found |= (items[idx] == item);
+    }
+    if constexpr (G == 64) return __ballot(found) != 0ull;
+    else return group_ballot<G>(found) != 0u;
+}
+
 // MT19937 step on a state kept in global memory (serial mode, one lane).  Published algorithm of
 // Matsumoto & Nishimura; the reference vendors it as rankfm/mt19937ar/mt19937ar.c:105-140.
 __device__ inline uint32_t mt_next_global(uint32_t *st) {
@@ -249,7 +284,7 @@ struct RowStep {
             for (;;) {
                 j = (int32_t)rfm_draw_to_item(rfm_draw(row_key, attempt), (uint32_t)a.n_items);
                 ++attempt;
-                if (!is_member(a.csr_items, lo, hi, j)) break;
+                if (!is_member_group<G>(a.csr_items, lo, hi, j, sub)) break;
                 if (attempt >= kMaxAttempts) { if (sub == 0) atomicOr(a.error_flags, 1u); break; }
             }
         }
