@@ -164,6 +164,32 @@ __device__ __forceinline__ bool is_member_group(const int32_t *__restrict__ item
     else return group_ballot<G>(found) != 0u;
 }
 
+// four candidates against one user's list: the list is read once
+template <int G>
+__device__ __forceinline__ void members4_group(const int32_t *__restrict__ items, int64_t lo, int64_t hi, const int32_t (&c)[4],
+                                               bool (&m)[4], int sub) {
+    if (hi - lo <= 4 * G) {
+        bool f[4] = {false, false, false, false};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t idx = lo + sub + (int64_t)G * k;
+            if (idx < hi) {
+                const int32_t v = items[idx];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[q] |= (v == c[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (G == 64) m[q] = __ballot(f[q]) != 0ull;
+            else m[q] = group_ballot<G>(f[q]) != 0u;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = is_member_group<G>(items, lo, hi, c[q], sub);
+    }
+}
+
 // MT19937 step on a state kept in global memory (serial mode, one lane).  Published algorithm of
 // Matsumoto & Nishimura; the reference vendors it as rankfm/mt19937ar/mt19937ar.c:105-140.
 __device__ inline uint32_t mt_next_global(uint32_t *st) {
@@ -322,7 +348,11 @@ struct RowStep {
         float min_pu = 1e6f;
         int32_t j = -1;
         int sampled = 0;
-        for (int s = 1; s <= a.max_samples; ++s) {
+        constexpr bool BATCH_WARP = !SERIAL && !FEAT;
+        // first draw (all of BPR): one candidate at a time
+        int s = 1;
+        bool done = false;
+        for (; s <= (BATCH_WARP ? 1 : a.max_samples); ++s) {
             const int32_t cand = next_negative(lo, hi, row_key, attempt);
             float vc[KPL], Bc[KPL], wc;
             const float pu = ut_ui - utility(vu, A, cand, vc, Bc, wc);   // :256-257
@@ -333,7 +363,53 @@ struct RowStep {
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) { vj[k] = vc[k]; if constexpr (FEAT) Bj[k] = Bc[k]; }
             }
-            if (pu < kMargin) break;                                      // :263-264
+            if (pu < kMargin) { done = true; break; }                     // :263-264
+        }
+        if constexpr (BATCH_WARP) {
+            // Later draws four at a time: the draw stream is keyed by (row, attempt), so looking ahead is free.  Four raw
+            // draws are checked against the user's list in one pass, the survivors' rows are fetched together and then
+            // examined IN DRAW ORDER with the reference's rule (first violator stops; draws after it are discarded).
+            s = 2;
+            while (!done && s <= a.max_samples) {
+                int32_t c[4];
+                bool mem[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[q] = (int32_t)rfm_draw_to_item(rfm_draw(row_key, attempt + q), (uint32_t)a.n_items);
+                attempt += 4;
+                members4_group<G>(a.csr_items, lo, hi, c, mem, sub);
+                float vc[4][KPL], wc[4], part[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    part[q] = 0.0f;
+                    wc[q] = 0.0f;
+                    if (!mem[q]) {
+                        load_row<FRESH>(a.v_i + (size_t)c[q] * F, vc[q]);
+                        wc[q] = load_f32<FRESH>(a.w_i + c[q]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (!mem[q]) {
+#pragma unroll
+                        for (int k = 0; k < KPL; ++k) part[q] += vu[k] * vc[q][k];
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) part[q] = group_sum<G>(part[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (done || mem[q] || s > a.max_samples) continue;
+                    const float pu = ut_ui - (wc[q] + part[q]);
+                    sampled = s;
+                    ++s;
+                    if (pu < min_pu) {
+                        min_pu = pu; j = c[q]; wj = wc[q];
+#pragma unroll
+                        for (int k = 0; k < KPL; ++k) vj[k] = vc[q][k];
+                    }
+                    if (pu < kMargin) done = true;
+                }
+                if (attempt >= kMaxAttempts) { if (sub == 0) atomicOr(a.error_flags, 1u); break; }
+            }
         }
         const float pu = min_pu;                                          // :267-268
         const float multiplier = a.multiplier[sampled];                   // :269 (integer division inside the log)
