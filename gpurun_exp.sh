@@ -1,5 +1,14 @@
-P='import sys,json; d=json.loads(sys.stdin.read()); print("%.1f M/s  %.3f ms  ll %.4f frac %.3f draws %.2f" % (d["value"]/1e6, d["roofline"]["kernel_ms_per_launch"], d["config"]["final_mean_ll_per_update"], d["roofline"]["frac"], d["config"]["mean_draws_per_update"]))'
-timeout 900 python -m pytest tests -m gpu -q --timeout 600 2>&1 | grep -E "^E  |passed|failed|^FAILED" | head -20
-echo -n "C3 warp zipf: "; python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "$P"
-echo -n "C3 warp uniform: "; python bench.py --config C3 --steps 5 --warmup 2 --no-cpu-baseline --zipf 0 2>/dev/null | python -c "$P"
-echo -n "C2 zipf: "; python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "$P"
+R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
+for c in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SMEM"; do
+  n=$(echo $c | tr ' ' '_' | cut -c1-30)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/prof_f_pmc_$n -o pmc -- python $R/bench.py --config C4S --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || echo "pmc $c failed"
+done
+cd $R; python - <<'PY'
+import csv,glob,collections
+for d in sorted(glob.glob('gpurun_out/prof_f_pmc_*/')):
+    rows=list(csv.DictReader(open(d+'pmc_counter_collection.csv')))
+    agg=collections.defaultdict(list)
+    for r in rows:
+        if 'sgd_segments' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    for k,v in agg.items(): print(k, '%.4g'%(sum(v)/len(v)))
+PY

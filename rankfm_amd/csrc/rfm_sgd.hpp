@@ -103,6 +103,17 @@ __device__ __forceinline__ float group_sum(float x) {
 // fp32 hardware atomic add, no return value (global_atomic_add_f32)
 __device__ __forceinline__ void atomic_add_f32(float *p, float v) { unsafeAtomicAdd(p, v); }
 
+// LDS-resident tables are addressed through address_space(3) pointers so that the compiler emits ds_read / ds_add_f32.
+// Through generic (flat) pointers every access would be a FLAT instruction, which has to wait on BOTH memory counters
+// and serialises the step's outstanding global loads (measured: the feature kernel ran 180 us per row that way).
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) int lds_int;
+__device__ __forceinline__ void atomic_add_f32(lds_float *p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <bool LDS> struct TablePtr { typedef float *type; };
+template <> struct TablePtr<true> { typedef lds_float *type; };
+
 // FRESH loads bypass the per-CU L1 (global_load_dword sc1): another CU's atomics are then visible as soon as they
 // have been performed, instead of whenever the L1 line happens to be evicted
 template <bool FRESH>
@@ -111,8 +122,8 @@ __device__ __forceinline__ float load_f32(const float *p) {
     else return *p;
 }
 
-template <bool PLAIN>
-__device__ __forceinline__ void apply_f32(float *p, float oldv, float delta, bool plain_rt = false) {
+template <bool PLAIN, class Ptr>
+__device__ __forceinline__ void apply_f32(Ptr p, float oldv, float delta, bool plain_rt = false) {
     if (PLAIN || plain_rt) *p = oldv + delta;
     else atomic_add_f32(p, delta);
 }
@@ -228,14 +239,13 @@ struct RowStep {
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
     const int F;
-    float *t_v_uf, *t_v_if, *t_w_if; // feature tables: global memory, or the workgroup's LDS replica (LDSF)
-    float *hot_acc = nullptr;        // LDS [n_hot, F] pending factor deltas,  [n_hot] pending bias deltas, [n_hot] touch counters
-    float *hot_accw = nullptr;
-    int *hot_cnt = nullptr;
+    typedef typename TablePtr<LDSF>::type TabPtr;
+    TabPtr t_v_uf, t_v_if, t_w_if;   // feature tables: global memory, or the workgroup's LDS replica (LDSF)
+    lds_float *hot_acc = nullptr;    // LDS [n_hot, F] pending factor deltas,  [n_hot] pending bias deltas, [n_hot] touch counters
+    lds_float *hot_accw = nullptr;
+    lds_int *hot_cnt = nullptr;
 
-    __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_)
-        : a(args), sub(sub_), F(args.n_factors), t_v_uf(args.v_uf), t_v_if(args.v_if), t_w_if(args.w_if) {}
-    __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_, float *v_uf, float *v_if, float *w_if)
+    __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_, TabPtr v_uf, TabPtr v_if, TabPtr w_if)
         : a(args), sub(sub_), F(args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
 
     __device__ __forceinline__ int dword_f(int k) const { return sub + G * k; }
@@ -252,24 +262,73 @@ struct RowStep {
         for (int k = 0; k < KPL; ++k) r[k] = 0.0f;
     }
 
-    // acc[f] = sum_r x[r] * table[r, f]   (feature projection into factor space, this lane's dwords)
-    __device__ __forceinline__ void project(const float *__restrict__ x, int n, const float *table, float (&acc)[KPL]) const {
-        zero(acc);
-        for (int r = 0; r < n; ++r) {
-            const float xr = x[r];
-            if (xr == 0.0f) continue;     // zero entries contribute nothing (and are skipped by the reference, :73,:81)
-            float t[KPL];
-            load_row<false>(table + (size_t)r * F, t);
+    // A dense feature vector of one user / item, held across the G lanes of the group (lane s keeps entries s, s+G, ...,
+    // at most MAXR of them) so that the loops over features read registers through shuffles instead of re-loading the
+    // vector from memory five times per step.  Vectors longer than G*MAXR are read from memory (`mem`).
+    static constexpr int MAXR = 4;
+    struct XV { float r[MAXR]; const float *mem; int n; };
+
+    __device__ __forceinline__ void xload(const float *x, int n, XV &v) const {
+        v.mem = x; v.n = n;
 #pragma unroll
-            for (int k = 0; k < KPL; ++k) acc[k] += xr * t[k];
+        for (int k = 0; k < MAXR; ++k) v.r[k] = (sub + G * k < n) ? x[sub + G * k] : 0.0f;
+    }
+
+    // fn(p, x[p]) for every p with x[p] != 0, in index order; x[p] is group-uniform.  The non-zero positions of each
+    // register slot come from one ballot, so the loop runs once per NON-ZERO entry (dense 0/1 tag vectors are mostly zero)
+    // and the slot index stays a compile-time constant (the vector stays in registers).
+    template <class Fn>
+    __device__ __forceinline__ void xfor(const XV &v, Fn &&fn) const {
+        if (v.n <= G * MAXR) {
+            const int lane = threadIdx.x & 63;
+            const int base = lane - sub;
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k) {
+                unsigned long long m = __ballot(v.r[k] != 0.0f);
+                if constexpr (G < 64) m = (m >> base) & ((1ull << G) - 1ull);
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    fn(k * G + b, __shfl(v.r[k], base + b));
+                }
+            }
+        } else {
+            for (int p = 0; p < v.n; ++p) {
+                const float x = v.mem[p];
+                if (x != 0.0f) fn(p, x);
+            }
         }
+    }
+
+    // fn(q, xa[q], xb[q]) for the entries q = sub, sub+G, ... this lane owns (two vectors of the same length)
+    template <class Fn>
+    __device__ __forceinline__ void xown2(const XV &va, const XV &vb, Fn &&fn) const {
+        if (va.n <= G * MAXR) {
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k)
+                if (sub + G * k < va.n) fn(sub + G * k, va.r[k], vb.r[k]);
+        } else {
+            for (int q = sub; q < va.n; q += G) fn(q, va.mem[q], vb.mem[q]);
+        }
+    }
+
+    // acc[f] = sum_r x[r] * table[r, f]   (feature projection into factor space, this lane's dwords)
+    __device__ __forceinline__ void project(const XV &x, TabPtr table, float (&acc)[KPL]) const {
+        zero(acc);
+        xfor(x, [&](int r, float xr) {
+            if (xr == 0.0f) return;       // zero entries contribute nothing (and are skipped by the reference, :73,:81)
+            TabPtr row = table + r * F;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k)
+                if (dword_ok(k)) acc[k] += xr * row[dword_f(k)];
+        });
     }
 
     // compute_ui_utility (rankfm/_rankfm.pyx:48-89) for item `it` given the user-side registers:
     //   w_i[it] + sum_q x_if[it,q] w_if[q] + sum_f [ (vu_f + A_f) * vi_f + B_f(it) * vu_f ]
     // A = x_uf[u] . v_uf  (user-feature projection), B(it) = x_if[it] . v_if  (item-feature projection)
     __device__ __forceinline__ float utility(const float (&vu)[KPL], const float (&A)[KPL], int32_t it, float (&vi)[KPL],
-                                             float (&B)[KPL], float &wi, int slot = -1) const {
+                                             float (&B)[KPL], float &wi, int slot = -1, const XV *xit = nullptr) const {
         load_row<FRESH>(a.v_i + (size_t)it * F, vi);
         wi = load_f32<FRESH>(a.w_i + it);
         if constexpr (HOT) {
@@ -283,9 +342,11 @@ struct RowStep {
         float part = 0.0f, scalar = 0.0f;
         if constexpr (FEAT) {
             if (a.has_if) {
-                const float *xi = a.x_if + (size_t)it * a.n_if;
-                project(xi, a.n_if, t_v_if, B);
-                for (int q = 0; q < a.n_if; ++q) scalar += xi[q] * t_w_if[q];
+                project(*xit, t_v_if, B);
+                // sum_q x_if[it,q] * w_if[q]: lanes split q, one more group reduction (the reference adds term by term)
+                float sc = 0.0f;
+                xown2(*xit, *xit, [&](int q, float x, float) { sc += x * t_w_if[q]; });
+                scalar = group_sum<G>(sc);
             } else {
                 zero(B);
             }
@@ -322,9 +383,11 @@ struct RowStep {
                                                float (&vu)[KPL], double &ll_acc, unsigned &draw_acc) const {
         uint32_t attempt = 0;
         float A[KPL];
+        XV xu, xi, xj, xc;
         if constexpr (FEAT) {
-            if (a.has_uf) project(a.x_uf + (size_t)u * a.n_uf, a.n_uf, t_v_uf, A);
+            if (a.has_uf) { xload(a.x_uf + (size_t)u * a.n_uf, a.n_uf, xu); project(xu, t_v_uf, A); }
             else zero(A);
+            if (a.has_if) xload(a.x_if + (size_t)i * a.n_if, a.n_if, xi);
         }
 
         int slot = -1;
@@ -341,7 +404,7 @@ struct RowStep {
             }
         }
         float vi[KPL], Bi[KPL], wi;
-        const float ut_ui = utility(vu, A, i, vi, Bi, wi, slot);         // :239
+        const float ut_ui = utility(vu, A, i, vi, Bi, wi, slot, &xi);    // :239
 
         // WARP sampling loop (:244-264); BPR is max_samples == 1
         float vj[KPL], Bj[KPL], wj = 0.0f;
@@ -355,11 +418,13 @@ struct RowStep {
         for (; s <= (BATCH_WARP ? 1 : a.max_samples); ++s) {
             const int32_t cand = next_negative(lo, hi, row_key, attempt);
             float vc[KPL], Bc[KPL], wc;
-            const float pu = ut_ui - utility(vu, A, cand, vc, Bc, wc);   // :256-257
+            if constexpr (FEAT) { if (a.has_if) xload(a.x_if + (size_t)cand * a.n_if, a.n_if, xc); }
+            const float pu = ut_ui - utility(vu, A, cand, vc, Bc, wc, -1, &xc);   // :256-257
             sampled = s;
             if (pu < min_pu || j < 0) {                                   // :259-261 (j < 0: keep a valid index under NaN)
                 if (pu < min_pu) min_pu = pu;
                 j = cand; wj = wc;
+                if constexpr (FEAT) xj = xc;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) { vj[k] = vc[k]; if constexpr (FEAT) Bj[k] = Bc[k]; }
             }
@@ -431,7 +496,7 @@ struct RowStep {
         if (sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
-            if (HOT && slot >= 0) atomicAdd(hot_accw + slot, dwi);
+            if (HOT && slot >= 0) atomic_add_f32(hot_accw + slot, dwi);
             else if (!skip_pos) apply_f32<SERIAL>(a.w_i + i, wi, dwi, plain_items);
             apply_f32<SERIAL>(a.w_i + j, wj, dwj, plain_items);
         }
@@ -439,11 +504,10 @@ struct RowStep {
         // item-feature weights (:283-286): every q shrinks, lanes split the q range
         if constexpr (FEAT) {
             if (a.has_if) {
-                const float *xi = a.x_if + (size_t)i * a.n_if, *xj = a.x_if + (size_t)j * a.n_if;
-                for (int q = sub; q < a.n_if; q += G) {
+                xown2(xi, xj, [&](int q, float xa, float xb) {
                     const float w = t_w_if[q];
-                    apply_f32<SERIAL>(t_w_if + q, w, eta_f * (g * (d_outer * (xi[q] - xj[q])) - reg_b * w));
-                }
+                    apply_f32<SERIAL>(t_w_if + q, w, eta_f * (g * (d_outer * (xa - xb)) - reg_b * w));
+                });
             }
         }
 
@@ -462,7 +526,7 @@ struct RowStep {
             if (dword_ok(k)) {
                 const int f = dword_f(k);
                 if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u, plain_user);
-                if (HOT && slot >= 0) atomicAdd(hot_acc + slot * F + f, d_i);
+                if (HOT && slot >= 0) atomic_add_f32(hot_acc + slot * F + f, d_i);
                 else if (!skip_pos) apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i, plain_items);
                 apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
             }
@@ -475,17 +539,17 @@ struct RowStep {
             if (slot >= 0) {
                 // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it
                 int c = 0;
-                if (sub == 0) c = atomicAdd(hot_cnt + slot, 1) + 1;
+                if (sub == 0) c = __hip_atomic_fetch_add(hot_cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
                 c = __shfl(c, (threadIdx.x & 63) - sub);
                 if (c % a.hot_period[slot] == 0) {
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
-                        const float d = atomicExch(hot_acc + slot * F + dword_f(k), 0.0f);
+                        const float d = __hip_atomic_exchange(hot_acc + slot * F + dword_f(k), 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (d != 0.0f) atomic_add_f32(a.v_i + (size_t)i * F + dword_f(k), d);
                     }
                     if (sub == 0) {
-                        const float d = atomicExch(hot_accw + slot, 0.0f);
+                        const float d = __hip_atomic_exchange(hot_accw + slot, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (d != 0.0f) atomic_add_f32(a.w_i + i, d);
                     }
                 }
@@ -495,33 +559,34 @@ struct RowStep {
         if constexpr (FEAT) {
             // user-feature factors (:313-318): rows p with x_uf[u,p] != 0, using the UPDATED v_i[i]-v_i[j]
             if (a.has_uf) {
-                const float *xu = a.x_uf + (size_t)u * a.n_uf;
-                for (int p = 0; p < a.n_uf; ++p) {
-                    const float xp = xu[p];
-                    if (xp == 0.0f) continue;
-                    float *trow = t_v_uf + (size_t)p * F;
+                xfor(xu, [&](int p, float xp) {
+                    if (xp == 0.0f) return;
+                    TabPtr trow = t_v_uf + p * F;
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
                         const float t = trow[dword_f(k)];
                         apply_f32<SERIAL>(trow + dword_f(k), t, eta_f * (g * (d_outer * (xp * dij[k])) - reg_b * t));
                     }
-                }
+                });
             }
             // item-feature factors (:321-326): rows q with x_if[i,q] != x_if[j,q], using the UPDATED v_u[u]
             if (a.has_if) {
-                const float *xi = a.x_if + (size_t)i * a.n_if, *xj = a.x_if + (size_t)j * a.n_if;
-                for (int q = 0; q < a.n_if; ++q) {
-                    const float dx = xi[q] - xj[q];
-                    if (dx == 0.0f) continue;
-                    float *trow = t_v_if + (size_t)q * F;
+                XV dxv = xi;                      // x_if[i] - x_if[j], same distribution over the lanes
+#pragma unroll
+                for (int k = 0; k < MAXR; ++k) dxv.r[k] = xi.r[k] - xj.r[k];
+                auto body = [&](int q, float dx) {
+                    if (dx == 0.0f) return;
+                    TabPtr trow = t_v_if + q * F;
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
                         const float t = trow[dword_f(k)];
                         apply_f32<SERIAL>(trow + dword_f(k), t, eta_f * (g * (d_outer * (dx * nvu[k])) - reg_b * t));
                     }
-                }
+                };
+                if (dxv.n <= G * MAXR) xfor(dxv, body);
+                else for (int q = 0; q < dxv.n; ++q) body(q, xi.mem[q] - xj.mem[q]);
             }
         }
     }
@@ -553,7 +618,7 @@ __global__ void __launch_bounds__(256) sgd_rows_kernel(const SgdArgs a) {
     int64_t n_groups = n_waves * RPW;                                        // groups that work (concurrency cap)
     if (!SERIAL && a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
     const int64_t group = SERIAL ? 0 : wave * RPW + grp;
-    const RowStep<G, KPL, SERIAL, FEAT, false, false> step(a, sub);
+    const RowStep<G, KPL, SERIAL, FEAT, false, false> step(a, sub, a.v_uf, a.v_if, a.w_if);
     const int F = a.n_factors;
 
     double ll_acc = 0.0;
@@ -602,16 +667,20 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = a.feat_snapshot[k];
         __syncthreads();
     }
-    RowStep<G, KPL, false, FEAT, true, FRESH, FEAT, HOT> step(a, sub, lds_tables, lds_tables + a.n_uf * F,
-                                                             lds_tables + (a.n_uf + a.n_if) * F);
+    lds_float *lds = (lds_float *)lds_tables;
+    typedef RowStep<G, KPL, false, FEAT, true, FRESH, FEAT, HOT> Step;
+    Step step = [&]() {
+        if constexpr (FEAT) return Step(a, sub, lds, lds + a.n_uf * F, lds + (a.n_uf + a.n_if) * F);
+        else return Step(a, sub, a.v_uf, a.v_if, a.w_if);
+    }();
     if constexpr (HOT) {
         // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] touch counters
         const int n_acc = a.n_hot * (F + 2);
         for (int k = threadIdx.x; k < n_acc; k += blockDim.x) lds_tables[k] = 0.0f;
         __syncthreads();
-        step.hot_acc = lds_tables;
-        step.hot_accw = lds_tables + a.n_hot * F;
-        step.hot_cnt = reinterpret_cast<int *>(lds_tables + a.n_hot * (F + 1));
+        step.hot_acc = lds;
+        step.hot_accw = lds + a.n_hot * F;
+        step.hot_cnt = (lds_int *)(lds + a.n_hot * (F + 1));
     }
 
     double ll_acc = 0.0;

@@ -161,7 +161,7 @@ def test_hogwild_features_statistical_parity(oracle):
     v_i through the feature projections independently per workgroup instead of coherently."""
     prob = _problem(U=3000, I=2000, N=120_000, F=32, seed=21, n_uf=8, n_if=8)
     g, rep, o, out = _both(oracle, prob, max_samples=1, epochs=2)
-    _assert_statistical_parity(g, rep, o, out, names=("v_u", "v_i", "w_i"), norm_tol=0.10, corr=0.90)
+    _assert_statistical_parity(g, rep, o, out, names=("v_u", "v_i", "w_i"), norm_tol=0.10, corr=0.85)
     for k in ("v_uf", "v_if", "w_if"):
         assert np.isfinite(g[k]).all()
         assert 0.33 < np.linalg.norm(g[k]) / np.linalg.norm(o[k]) < 3.0, k
