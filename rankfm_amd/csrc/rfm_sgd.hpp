@@ -234,7 +234,8 @@ __device__ __forceinline__ float log_sigmoid(float x) {
 // ---------------------------------------------------------------------------------------------
 //   LDSF     the dense feature tables (v_uf, v_if, w_if) are this workgroup's LDS replica: plain step size, LDS atomics
 //   HOT      updates of hot positive items are accumulated in the workgroup's LDS and published every few touches
-template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false>
+//   WARPB    compile the batched WARP draw loop (max_samples > 1); the BPR instantiation stays at ~76 VGPRs without it
+template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false, bool WARPB = true>
 struct RowStep {
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
@@ -411,11 +412,11 @@ struct RowStep {
         float min_pu = 1e6f;
         int32_t j = -1;
         int sampled = 0;
-        constexpr bool BATCH_WARP = !SERIAL && !FEAT;
+        constexpr bool BATCH_WARP = !SERIAL && !FEAT && WARPB;
         // first draw (all of BPR): one candidate at a time
         int s = 1;
         bool done = false;
-        for (; s <= (BATCH_WARP ? 1 : a.max_samples); ++s) {
+        for (; s <= ((BATCH_WARP || (!SERIAL && !FEAT && !WARPB)) ? 1 : a.max_samples); ++s) {
             const int32_t cand = next_negative(lo, hi, row_key, attempt);
             float vc[KPL], Bc[KPL], wc;
             if constexpr (FEAT) { if (a.has_if) xload(a.x_if + (size_t)cand * a.n_if, a.n_if, xc); }
@@ -652,7 +653,7 @@ __global__ void __launch_bounds__(256) sgd_rows_kernel(const SgdArgs a) {
 // larger workgroups mean fewer replicas for the same number of interactions in flight.
 // The HOT instantiation (no features) also uses 1024 threads: the hot-row accumulators are per workgroup, and fewer,
 // larger workgroups combine more touches per publication at the same amount of unpublished work.
-template <int G, int KPL, bool FEAT, bool FRESH, bool HOT = false>
+template <int G, int KPL, bool FEAT, bool FRESH, bool HOT = false, bool WARPB = true>
 __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
@@ -668,7 +669,7 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         __syncthreads();
     }
     lds_float *lds = (lds_float *)lds_tables;
-    typedef RowStep<G, KPL, false, FEAT, true, FRESH, FEAT, HOT> Step;
+    typedef RowStep<G, KPL, false, FEAT, true, FRESH, FEAT, HOT, WARPB> Step;
     Step step = [&]() {
         if constexpr (FEAT) return Step(a, sub, lds, lds + a.n_uf * F, lds + (a.n_uf + a.n_if) * F);
         else return Step(a, sub, a.v_uf, a.v_if, a.w_if);
