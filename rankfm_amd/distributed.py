@@ -11,8 +11,9 @@ The reference is single-process (no counterpart to cite); the design follows SUR
     7 x 153 GB/s xGMI links against epochs of tens to hundreds of ms, so one large collective per epoch is the right
     granularity for point-to-point xGMI.
   * `scale` is the same stale-step damping the single-GPU engine applies to hot rows (DESIGN.md "staleness"): a row
-    that received n updates across all ranks during the window gets min(1, M / n) of the summed delta, never less
-    than the plain average 1/world.  Rarely-touched rows therefore end the epoch with every rank's updates applied
+    that received n updates across all ranks during the window gets min(1, M / n) of the summed delta (M = 32: an
+    item's bias and factors settle within tens of updates, and two ranks' settled moves must not be added: measured
+    +10 % on |w_i| with M = 128 in the 2-shard emulation test), never less than the plain average 1/world.  Rarely-touched rows therefore end the epoch with every rank's updates applied
     (sum of deltas), rows every rank hammered end at the ranks' average (summing K near-converged local moves
     would overshoot K-fold), and the dense feature tables are always averaged.
 
@@ -70,7 +71,7 @@ class SharedTables:
         self._starts, self._sizes, self._shapes = starts, sizes, shapes
         self.merge_scale = None          # per-element damping of the summed deltas (None = plain sum)
 
-    def set_merge_damping(self, item_counts_all_ranks, world_size, damping=128.0):
+    def set_merge_damping(self, item_counts_all_ranks, world_size, damping=32.0):
         """per-element scale of the summed deltas: min(1, M / n_i) clipped below at 1/world_size for item i that all
         ranks together update n_i times per exchange window; 1/world_size (average) for the dense feature tables"""
         n = torch.as_tensor(np.asarray(item_counts_all_ranks, dtype=np.float64), dtype=torch.float32, device=self.flat.device)
@@ -128,7 +129,7 @@ class ShardedTrainer:
         return out
 
 
-def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=128.0,
+def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=32.0,
                         **session_kw):
     """wire a rank's shard to the HIP engine: weights are views into the flat bucket, so the engine's in-place
     atomics and the all-reduce act on the same memory"""

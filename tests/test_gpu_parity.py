@@ -282,3 +282,55 @@ def test_verbose_prints_like_the_reference(capsys):
     assert out.count("training epoch:") == int(g["epochs"]) and "log likelihood:" in out
     vals = [float(x.split(":")[1]) for x in out.splitlines() if x.startswith("log likelihood")]
     np.testing.assert_allclose(vals, g["ll_printed"], atol=0.03)
+
+
+def test_two_user_shards_with_damped_delta_merge_track_the_oracle(oracle):
+    """The multi-GPU algorithm (rankfm_amd/distributed.py) emulated on ONE GPU: two user shards are trained by two resident
+    sessions from the same item tables, and after every epoch the item-side deltas are merged exactly as the RCCL exchange
+    does (start + scale * sum of deltas, SharedTables).  The result must track single-run sequential training of the whole
+    data: during the first epoch each shard is blind to the other's item updates (one exchange per epoch), so that epoch's
+    log-likelihood lags by a few percent (6 % allowed); from the second epoch on 2 %; factor norms within 5 % (the item biases,
+    which settle fastest, are the most sensitive: +3 % here)."""
+    import torch
+    from rankfm_amd import synthetic
+    from rankfm_amd.distributed import SHARED_NAMES, SharedTables, shard_boundaries, take_user_shard
+    from rankfm_amd.engine import DeviceSession
+    U, I, N, F, E = 20000, 8000, 1_000_000, 32, 3
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=2)
+    w = synthetic.init_weights(U, I, F, seed=3)
+    sw = np.ones(N, np.float32)
+    z_i = np.zeros((I, 1), np.float32)
+    dev = torch.device("cuda", 0)
+    bounds = shard_boundaries(csr.offsets, 2)
+    shards = [take_user_shard(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), w["v_u"], bounds[r], bounds[r + 1]) for r in range(2)]
+    tables = [SharedTables({k: w[k] for k in SHARED_NAMES}, dev) for _ in range(2)]
+    counts = np.bincount(pairs[:, 1], minlength=I)
+    for t in tables:
+        t.set_merge_damping(counts, 2)
+    sessions = []
+    for r in range(2):
+        weights = dict(tables[r].views)
+        weights["v_u"] = torch.as_tensor(shards[r]["v_u"]).to(dev)
+        sessions.append(DeviceSession(shards[r]["interactions"], shards[r]["sample_weight"], shards[r]["csr_offsets"], shards[r]["csr_items"],
+                                      shards[r]["x_uf"], z_i, weights, seed=40 + r, device=dev))
+    ll = np.zeros(E)
+    for e in range(E):
+        for t in tables:
+            t.begin_epoch()
+        for r in range(2):
+            ll[e] += sessions[r].run(epochs=1, epoch_begin=e)["log_likelihood"][0]
+        # what all_reduce_deltas does on each rank
+        total = (tables[0].flat - tables[0].start) + (tables[1].flat - tables[1].start)
+        merged = tables[0].start + tables[0].merge_scale * total
+        for t in tables:
+            t.flat.copy_(merged)
+    o = {k: v.copy() for k, v in w.items()}
+    out = oracle.fit(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), z_i, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"],
+                     o["v_if"], 0.01, 0.1, 0.1, "constant", 0.25, 1, E, perms=None, rng_mode=oracle.RNG_COUNTER, seed=1, membership="binary")
+    np.testing.assert_allclose(ll[:1], out["ll"][:1], rtol=0.06)
+    np.testing.assert_allclose(ll[1:], out["ll"][1:], rtol=0.02)
+    v_i = tables[0].views["v_i"].cpu().numpy()
+    w_i = tables[0].views["w_i"].cpu().numpy()
+    v_u = np.concatenate([s.weights["v_u"].cpu().numpy() for s in sessions])
+    for got, want, name in ((v_i, o["v_i"], "v_i"), (w_i, o["w_i"], "w_i"), (v_u, o["v_u"], "v_u")):
+        assert abs(np.linalg.norm(got) - np.linalg.norm(want)) <= 0.05 * np.linalg.norm(want), name
