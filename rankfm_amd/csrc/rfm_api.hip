@@ -390,13 +390,15 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // atomics serialise on one or two cache lines -- on BASELINE config 2 the ten hottest items cost half the epoch -- so
     // the HOT kernel accumulates them per workgroup in LDS.  (bit 2 of debug_flags switches this off.)
     std::vector<int> hot_order;
-    if (damp && build_plan && use_segments && !feat && !(cfg->debug_flags & 4) && cfg->n_factors <= 126) {
+    if (damp && build_plan && use_segments && !feat && !(cfg->debug_flags & 4)) {
         const double g0 = (double)(g_sm_count > 0 ? g_sm_count : 256) * 16.0 * (64 / shape->group);
         const double kHotMin = 16.0;
         for (int i = 0; i < cfg->n_items; ++i)
             if ((double)item_count[i] * g0 / (double)N >= kHotMin) hot_order.push_back(i);
         std::sort(hot_order.begin(), hot_order.end(), [&](int x, int y) { return item_count[x] > item_count[y] || (item_count[x] == item_count[y] && x < y); });
-        if ((int)hot_order.size() > kMaxHot) hot_order.resize(kMaxHot);
+        // LDS budget of the accumulators: 48 KiB per workgroup
+        const int max_hot = std::min(kMaxHot, 12288 / (cfg->n_factors + 2));
+        if ((int)hot_order.size() > max_hot) hot_order.resize(max_hot > 0 ? max_hot : 0);
         n_hot = (int)hot_order.size();
     }
     const bool use_hot = use_segments && !feat && !single_group && n_hot > 0;
