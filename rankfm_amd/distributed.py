@@ -152,3 +152,68 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
         return sess.run(epochs=1, epoch_begin=epoch)
 
     return ShardedTrainer(shared, epoch_fn, group=group, average=average), sess
+
+
+def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,
+                    group=None, device=None, merge_damping=32.0, make_trainer=None):
+    """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
+    the SAME arguments and the same numpy seed.
+
+    Every rank indexes the full data set (cheap, vectorised, identical on all ranks because numpy's RNG state is), takes the
+    user shard of its rank, trains it on its GPU and exchanges the item-side deltas once per epoch (ShardedTrainer).  At the
+    end the user factors are all-gathered, so every rank returns the complete fitted model with the reference's attribute
+    layout.  With world size 1 this is `model.fit(...)` on the resident-session path.
+
+    `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
+    CPU tests; `finish()` must return the shard's trained v_u as a numpy array.
+    """
+    assert isinstance(epochs, int) and epochs >= 1, "[epochs] must be a positive integer"
+    assert isinstance(verbose, bool), "[verbose] must be a boolean value"
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    model._reset_state()
+    model._init_all(interactions, user_features, item_features, sample_weight)
+    max_samples = 1 if model.loss == "bpr" else model.max_samples            # rankfm/rankfm.py:294-297
+    bounds = shard_boundaries(model.user_items.offsets, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    shard = take_user_shard(model.interactions, model.sample_weight, model.user_items.offsets, model.user_items.items, model.x_uf,
+                            model.v_u, lo, hi)
+    hyper = dict(alpha=model.alpha, beta=model.beta, learning_rate=model.learning_rate, learning_schedule=model.learning_schedule,
+                 learning_exponent=model.learning_exponent, max_samples=max_samples)
+    tables = {k: getattr(model, k) for k in SHARED_NAMES}
+    if make_trainer is None:
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        seed = int(np.random.randint(0, 2**31 - 1)) + rank if model.engine.seed is None else int(model.engine.seed) + rank
+        trainer, sess = make_device_trainer(shard, tables, model.x_if, hyper, device, group=group, merge_damping=merge_damping,
+                                            seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
+                                            want_penalty=verbose, hogwild_damping=model.engine.damping)
+        finish = lambda: sess.weights["v_u"].detach().cpu().numpy()          # noqa: E731
+    else:
+        trainer, finish = make_trainer(shard, tables, model.x_if, hyper, device, group)
+    broadcast_from_rank0([trainer.shared.flat], group)
+    for e in range(epochs):
+        out = trainer.run_epoch(e)
+        if verbose:
+            ll = torch.tensor([float(np.sum(out.get("log_likelihood", out.get("ll", [0.0]))))], dtype=torch.float64,
+                              device=trainer.shared.flat.device)
+            if world > 1:
+                dist.all_reduce(ll, group=group)
+            if rank == 0:
+                print("\ntraining epoch:", e)
+                print("log likelihood (un-penalised, all ranks):", round(float(ll.item()), 2))
+    # assemble the full model on every rank: item-side tables are already identical, user factors are all-gathered
+    for k in SHARED_NAMES:
+        getattr(model, k)[...] = trainer.shared.views[k].detach().cpu().numpy()
+    v_u_local = np.ascontiguousarray(finish(), dtype=np.float32)
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, (lo, hi, v_u_local), group=group)
+        for plo, phi, part in parts:
+            model.v_u[plo:phi] = part
+    else:
+        model.v_u[lo:hi] = v_u_local
+    assert np.isfinite(model.v_u).all() and np.isfinite(model.v_i).all(), "model weights are not finite"
+    model.epochs_trained += epochs
+    model.is_fit = True
+    return model

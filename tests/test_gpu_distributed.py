@@ -1,0 +1,55 @@
+"""The multi-GPU fit on the real engine with TWO ranks sharing the one GPU of the test box (gloo carries the exchange; the
+driver's scaling runs use one GPU per rank over RCCL).  Exercises make_device_trainer, the bucket all-reduce on device
+tensors, the damped merge and the final assembly of the model."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+U, I, N, F = 6000, 3000, 300_000, 32
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from rankfm_amd import EngineOptions, RankFM, synthetic
+    from rankfm_amd.distributed import fit_distributed
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pairs, _ = synthetic.make_interactions(U, I, N, seed=1)
+    m = RankFM(factors=F, engine=EngineOptions(seed=9))
+    np.random.seed(4)
+    fit_distributed(m, pairs, epochs=3, device=torch.device("cuda", 0))
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), v_u=m.v_u, v_i=m.v_i, w_i=m.w_i)
+    dist.destroy_process_group()
+
+
+def test_fit_distributed_two_ranks_one_gpu(tmp_path, oracle):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    for k in ("v_u", "v_i", "w_i"):
+        assert np.array_equal(a[k], b[k]) and np.isfinite(a[k]).all(), k
+    # and it learned what single-process sequential training learns (norms within 5 %, see test_two_user_shards_...)
+    from rankfm_amd import RankFM, synthetic
+    pairs, _ = synthetic.make_interactions(U, I, N, seed=1)
+    m = RankFM(factors=F)
+    np.random.seed(4)
+    m._init_all(pairs)
+    oracle.fit(m.interactions, m.sample_weight, m.user_items.offsets, m.user_items.items, m.x_uf, m.x_if, m.w_i, m.w_if, m.v_u, m.v_i,
+               m.v_uf, m.v_if, 0.01, 0.1, 0.1, "constant", 0.25, 1, 3, perms=None, rng_mode=oracle.RNG_COUNTER, seed=9, membership="binary")
+    for k in ("v_u", "v_i", "w_i"):
+        got, want = np.linalg.norm(a[k]), np.linalg.norm(getattr(m, k))
+        assert abs(got - want) <= 0.05 * want, (k, got, want)
