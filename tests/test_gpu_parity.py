@@ -223,7 +223,8 @@ def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
     _assert_statistical_parity(g, rep, o, out)
 
 
-def test_hogwild_conserves_item_factor_sums(c2_problem):
+@pytest.mark.parametrize("damping", [-1.0, 1e9])
+def test_hogwild_conserves_item_factor_sums(c2_problem, damping):
     """Size-independent property at BASELINE config-2 scale: with alpha -> 0 every step adds +d to v_i[i] and -d to
     v_i[j] (rankfm/_rankfm.pyx:309-310) and +/-g to w_i, so column sums of v_i and the sum of w_i are invariants of
     ANY interleaving -- provided no update is lost.  Atomic adds keep them; a racy read-modify-write would not."""
@@ -234,7 +235,9 @@ def test_hogwild_conserves_item_factor_sums(c2_problem):
     before = w["v_i"].astype(np.float64).sum(axis=0)
     sess = DeviceSession(pairs, np.ones(N, np.float32), csr.offsets, csr.items, np.zeros((U, 1), np.float32),
                          np.zeros((I, 1), np.float32), w, alpha=0.0, beta=0.0, max_samples=1, seed=1492,
-                         hogwild_damping=-1.0)      # damping rescales the positive item's step only: switch it off here
+                         hogwild_damping=damping)
+    # damping rescales the positive item's step only, so it must not act here: -1 switches it (and the hot-row LDS
+    # accumulation) off; 1e9 keeps every scale at 1 but leaves the hot-row accumulators ON -- they must not lose updates either
     rep = sess.run(epochs=1)
     h = sess.weights_to_host()
     after = h["v_i"].astype(np.float64).sum(axis=0)
