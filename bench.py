@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--damping", type=float, default=0.0, help="hogwild damping M (0 default, <0 off)")
     ap.add_argument("--debug-flags", type=int, default=0)
+    ap.add_argument("--syncs-per-epoch", type=int, default=1, help="item-delta exchanges per epoch (N > 1)")
     ap.add_argument("--factors", type=int, default=0, help="override the config's factor count (experiments)")
     ap.add_argument("--shape", type=int, default=0, help="experiment: 1-based index into the kernel shape table")
     args = ap.parse_args()
@@ -134,7 +135,7 @@ def main():
     hyper = dict(alpha=0.01, beta=0.1, learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25,
                  max_samples=cfg["max_samples"])
     trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
-                                        seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
+                                        syncs_per_epoch=args.syncs_per_epoch, seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
                                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
                                         update_mode=args.update_mode, shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check)
     broadcast_from_rank0([trainer.shared.flat])

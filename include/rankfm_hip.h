@@ -99,6 +99,8 @@ typedef struct rfm_fit_config {
     int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
                                       bit 1: factor-row loads bypass the per-CU L1,
                                       bit 2: no LDS accumulation of hot item rows */
+    int32_t epoch_part_index;      /* with epoch_parts > 1: run only part k (0-based) of each epoch's visiting order -- lets a */
+    int32_t epoch_parts;           /* multi-GPU caller exchange item deltas several times per epoch; 0 or 1 = whole epochs    */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
                                       scales) into the head of `workspace`; > 0: the value rfm_fit_report.plan_token returned
                                       by an earlier call on the SAME workspace, interactions, geometry and damping -- the

@@ -34,6 +34,7 @@ class FitConfig(C.Structure):
         ("n_workgroups", C.c_int32), ("rows_per_launch", C.c_int32),
         ("hogwild_damping", C.c_float),
         ("debug_update_mode", C.c_int32), ("debug_shape", C.c_int32), ("debug_flags", C.c_int32),
+        ("epoch_part_index", C.c_int32), ("epoch_parts", C.c_int32),
         ("plan_token", C.c_int64),
     ]
 

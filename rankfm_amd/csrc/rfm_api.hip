@@ -214,6 +214,7 @@ static int validate(const rfm_fit_config *c) {
     if (c->n_users < 1 || c->n_items < 2 || c->n_user_features < 1 || c->n_item_features < 1 || c->n_factors < 1)
         return RFM_ERR_BAD_ARG;
     if (c->max_samples < 1 || c->epochs < 1 || c->epoch_begin < 0) return RFM_ERR_BAD_ARG;
+    if (c->epoch_parts > 1 && (c->epoch_part_index < 0 || c->epoch_part_index >= c->epoch_parts)) return RFM_ERR_BAD_ARG;
     if (c->learning_schedule != RFM_SCHEDULE_CONSTANT && c->learning_schedule != RFM_SCHEDULE_INVSCALING)
         return RFM_ERR_UNKNOWN_SCHEDULE;
     if (c->mode != RFM_MODE_HOGWILD && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;
@@ -535,10 +536,16 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         const double rows_per_replica = (double)N / (double)launches / (double)(grid > 0 ? grid : 1);
         const bool select_replica = rows_per_replica * (double)a.eta * (double)a.reg_b >= 4.0;
         int window = 0;
-        for (int64_t p0 = 0; p0 < units; p0 += units_per_launch, ++window) {
+        // a caller may ask for one part of the epoch's order only (several delta exchanges per epoch on multi-GPU jobs)
+        int64_t u_begin = 0, u_end = units;
+        if (cfg->epoch_parts > 1) {
+            u_begin = units * cfg->epoch_part_index / cfg->epoch_parts;
+            u_end = units * (cfg->epoch_part_index + 1) / cfg->epoch_parts;
+        }
+        for (int64_t p0 = u_begin; p0 < u_end; p0 += units_per_launch, ++window) {
             a.feat_select_wg = (use_segments && feat && select_replica) ? (int)((e * launches + window) % grid) : -1;
             a.pos_begin = p0;
-            a.pos_end = p0 + units_per_launch < units ? p0 + units_per_launch : units;
+            a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
             if (use_segments && feat) {      // the replicas start from, and are merged against, the tables as of now
                 const size_t nu = (size_t)cfg->n_user_features * cfg->n_factors, ni = (size_t)cfg->n_item_features * cfg->n_factors;
                 RFM_HIP(hipMemcpyAsync(ws.feat_snapshot, b->v_uf, sizeof(float) * nu, hipMemcpyDeviceToDevice, stream));

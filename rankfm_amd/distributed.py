@@ -123,14 +123,28 @@ class ShardedTrainer:
         self.syncs_per_epoch = syncs_per_epoch
 
     def run_epoch(self, epoch):
-        self.shared.begin_epoch()
-        out = self.epoch_fn(self.shared.views, epoch)
-        self.shared.all_reduce_deltas(self.group, self.average)
-        return out
+        # one epoch = `syncs_per_epoch` slices of the visiting order, each followed by the delta exchange
+        if self.syncs_per_epoch <= 1:
+            self.shared.begin_epoch()
+            out = self.epoch_fn(self.shared.views, epoch)
+            self.shared.all_reduce_deltas(self.group, self.average)
+            return out
+        total = None
+        for k in range(self.syncs_per_epoch):
+            self.shared.begin_epoch()
+            out = self.epoch_fn(self.shared.views, epoch, part=(k, self.syncs_per_epoch))
+            self.shared.all_reduce_deltas(self.group, self.average)
+            if total is None:
+                total = {key: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for key, v in out.items()}
+            else:
+                for key in ("log_likelihood", "ll", "sgd_kernel_ms", "n_draws"):
+                    if key in out and out[key] is not None:
+                        total[key] = total[key] + out[key]
+        return total
 
 
 def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=32.0,
-                        **session_kw):
+                        syncs_per_epoch=1, **session_kw):
     """wire a rank's shard to the HIP engine: weights are views into the flat bucket, so the engine's in-place
     atomics and the all-reduce act on the same memory"""
     from .engine import DeviceSession
@@ -139,7 +153,8 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
         counts = torch.bincount(torch.as_tensor(np.asarray(shard["interactions"])[:, 1].astype(np.int64)),
                                 minlength=shared.views["w_i"].shape[0]).to(device=device, dtype=torch.float32)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-        shared.set_merge_damping(counts.cpu().numpy(), dist.get_world_size(group), merge_damping)
+        # the damping counts updates per exchange window
+        shared.set_merge_damping(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), merge_damping)
     weights = dict(shared.views)
     weights["v_u"] = torch.as_tensor(shard["v_u"]).to(device)
     sess = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"],
@@ -148,14 +163,14 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
     for k in SHARED_NAMES:
         assert sess.weights[k].data_ptr() == shared.views[k].data_ptr(), "shared table was copied out of the bucket"
 
-    def epoch_fn(_views, epoch):
-        return sess.run(epochs=1, epoch_begin=epoch)
+    def epoch_fn(_views, epoch, part=None):
+        return sess.run(epochs=1, epoch_begin=epoch, part=part)
 
-    return ShardedTrainer(shared, epoch_fn, group=group, average=average), sess
+    return ShardedTrainer(shared, epoch_fn, group=group, average=average, syncs_per_epoch=syncs_per_epoch), sess
 
 
 def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,
-                    group=None, device=None, merge_damping=32.0, make_trainer=None):
+                    group=None, device=None, merge_damping=32.0, syncs_per_epoch=1, make_trainer=None):
     """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
     the SAME arguments and the same numpy seed.
 
@@ -186,7 +201,7 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
             device = torch.device("cuda", torch.cuda.current_device())
         seed = int(np.random.randint(0, 2**31 - 1)) + rank if model.engine.seed is None else int(model.engine.seed) + rank
         trainer, sess = make_device_trainer(shard, tables, model.x_if, hyper, device, group=group, merge_damping=merge_damping,
-                                            seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
+                                            syncs_per_epoch=syncs_per_epoch, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
                                             want_penalty=verbose, hogwild_damping=model.engine.damping)
         finish = lambda: sess.weights["v_u"].detach().cpu().numpy()          # noqa: E731
     else:

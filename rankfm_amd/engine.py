@@ -66,8 +66,9 @@ class DeviceSession:
         self._plan_token = 0
         self.debug_flags = int(debug_flags)
 
-    def _config(self, epochs, epoch_begin):
+    def _config(self, epochs, epoch_begin, part=None):
         return _hip.FitConfig(
+            epoch_part_index=part[0] if part else 0, epoch_parts=part[1] if part else 0,
             hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token), debug_flags=self.debug_flags,
             debug_update_mode=self.update_mode, debug_shape=self.shape_override,
             n_interactions=self.n_interactions, n_users=self.n_users, n_items=self.n_items,
@@ -77,9 +78,9 @@ class DeviceSession:
             check_finite=self.check_finite, want_penalty=self.want_penalty,
             n_workgroups=self.n_workgroups, rows_per_launch=self.rows_per_launch, **self.hyper)
 
-    def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True):
+    def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True, part=None):
         """train `epochs` epochs in place on the resident tensors; returns the per-epoch report (numpy arrays)"""
-        cfg = self._config(epochs, epoch_begin)
+        cfg = self._config(epochs, epoch_begin, part)    # part = (k, n): only the k-th of n slices of each epoch's order
         need = _hip.lib().rfm_fit_workspace_bytes(C.byref(cfg))
         if need == 0:
             _hip.raise_for_status(_hip.lib().rfm_fit_supported(C.byref(cfg)))
