@@ -4,9 +4,10 @@
 //   rfm_recommend_*  replaces rankfm/_rankfm.pyx:393-460  (score all items per user, rank descending, optionally
 //                    skip the user's observed items, keep the first n_items)
 //
-// Both reuse the pointwise utility of compute_ui_utility (rankfm/_rankfm.pyx:48-89) in the factored form
+// Both use the pointwise utility of compute_ui_utility (rankfm/_rankfm.pyx:48-89) in the factored form
 //   U(u,i) = w_i[i] + x_if[i].w_if + < v_u[u] + x_uf[u].v_uf , v_i[i] > + < x_if[i].v_if , v_u[u] >
-// evaluated by 16-lane groups with lanes striding the factor dimension (coalesced row reads).
+// `_predict` evaluates it per pair with 16-lane groups (coalesced row reads); `_recommend` evaluates all items of a chunk of
+// users as one f32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) followed by a block-wide top-n.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -70,20 +71,106 @@ __global__ void __launch_bounds__(256) predict_kernel(const rfm_model_view m, lo
     }
 }
 
-// scores[slot, i] for a chunk of users; blockIdx.y = user slot
-__global__ void __launch_bounds__(256) user_scores_kernel(const rfm_model_view m, const float *__restrict__ users,
-                                                          long long user_begin, float *__restrict__ scores) {
-    const long long slot = blockIdx.y;
-    const float uf = users[user_begin + slot];
-    if (isnan(uf)) return;
-    const int u = (int)uf;
+// ---------------------------------------------------------------------------------------------
+// `_recommend` scoring as ONE f32 GEMM on the matrix cores (the one dense contraction of the package).
+//   score(u, i) = bias[i] + < Ueff[u, :], Veff[i, :] >
+//   Ueff[u] = [ v_u[u] + x_uf[u].v_uf | v_u[u] ]          Veff[i] = [ v_i[i] | x_if[i].v_if ]          (second halves only
+//   bias[i] = w_i[i] + x_if[i].w_if                                                                   with item features)
+// which is compute_ui_utility (rankfm/_rankfm.pyx:48-89) regrouped.  K is padded with zeros to a multiple of 32.
+// mfma_f32_32x32x2f32 is exact fp32 (an fmaf chain), so scores agree with the scalar kernel to summation order.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) build_veff_kernel(const rfm_model_view m, int kp, float *__restrict__ veff, float *__restrict__ bias) {
     const int sub = threadIdx.x & (kGroup - 1);
-    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
-    const int n_groups = (gridDim.x * blockDim.x) / kGroup;
-    float *out = scores + (size_t)slot * m.n_items;
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup, n_groups = (gridDim.x * blockDim.x) / kGroup;
+    const int F = m.n_factors;
     for (int i = group; i < m.n_items; i += n_groups) {
-        const float s = utility16(m, u, i, sub);
-        if (sub == 0) out[i] = s;
+        float *row = veff + (size_t)i * kp;
+        for (int f = sub; f < kp; f += kGroup) {
+            float v = 0.0f;
+            if (f < F) v = m.v_i[(size_t)i * F + f];
+            else if (m.has_item_features && f < 2 * F) {
+                const float *xi = m.x_if + (size_t)i * m.n_item_features;
+                for (int q = 0; q < m.n_item_features; ++q)
+                    if (xi[q] != 0.0f) v += xi[q] * m.v_if[(size_t)q * F + (f - F)];
+            }
+            row[f] = v;
+        }
+        float s = 0.0f;
+        if (m.has_item_features) {
+            const float *xi = m.x_if + (size_t)i * m.n_item_features;
+            for (int q = sub; q < m.n_item_features; q += kGroup) s += xi[q] * m.w_if[q];
+            s = group16_sum(s);
+        }
+        if (sub == 0) bias[i] = m.w_i[i] + s;
+    }
+}
+
+__global__ void __launch_bounds__(256) build_ueff_kernel(const rfm_model_view m, const float *__restrict__ users, long long user_begin,
+                                                        int n_slots, int kp, float *__restrict__ ueff) {
+    const int sub = threadIdx.x & (kGroup - 1);
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup, n_groups = (gridDim.x * blockDim.x) / kGroup;
+    const int F = m.n_factors;
+    for (int slot = group; slot < n_slots; slot += n_groups) {
+        const float uf = users[user_begin + slot];
+        float *row = ueff + (size_t)slot * kp;
+        const bool cold = isnan(uf);
+        const int u = cold ? 0 : (int)uf;
+        for (int f = sub; f < kp; f += kGroup) {
+            float v = 0.0f;
+            if (!cold && f < F) {
+                v = m.v_u[(size_t)u * F + f];
+                if (m.has_user_features) {
+                    const float *xu = m.x_uf + (size_t)u * m.n_user_features;
+                    for (int p = 0; p < m.n_user_features; ++p)
+                        if (xu[p] != 0.0f) v += xu[p] * m.v_uf[(size_t)p * F + f];
+                }
+            } else if (!cold && m.has_item_features && f < 2 * F) {
+                v = m.v_u[(size_t)u * F + (f - F)];
+            }
+            row[f] = v;
+        }
+    }
+}
+
+// scores[slot, i] = bias[i] + sum_k ueff[slot, k] * veff[i, k].  64 x 64 output tile per workgroup, 4 wavefronts in 2 x 2,
+// each wavefront one 32 x 32 accumulator (16 VGPRs) fed by v_mfma_f32_32x32x2_f32; K advances in LDS stages of 32.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kKT = 32, kLd = kKT + 1;       // +1: the 32 lanes of an operand read walk rows, stride 33 dwords is conflict-free
+
+__global__ void __launch_bounds__(256) scores_mfma_kernel(const float *__restrict__ ueff, const float *__restrict__ veff,
+                                                         const float *__restrict__ bias, int n_slots, int n_items, int kp,
+                                                         float *__restrict__ scores) {
+    __shared__ float sA[64 * kLd], sB[64 * kLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int slot0 = blockIdx.y * 64, item0 = blockIdx.x * 64;
+    f32x16 acc = {0};
+    for (int k0 = 0; k0 < kp; k0 += kKT) {
+        // stage 64 x 32 of each operand: 2048 floats per operand, 8 per thread, consecutive threads along k (coalesced 128 B rows)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int e = tid + 256 * r, row = e >> 5, col = e & 31;
+            const int s = slot0 + row, it = item0 + row;
+            sA[row * kLd + col] = s < n_slots ? ueff[(size_t)s * kp + k0 + col] : 0.0f;
+            sB[row * kLd + col] = it < n_items ? veff[(size_t)it * kp + k0 + col] : 0.0f;
+        }
+        __syncthreads();
+        // A operand: lane l holds A[row = l & 31][k = l >> 5]; B operand: lane l holds B[k = l >> 5][col = l & 31]
+        const float *pa = sA + (wr * 32 + (lane & 31)) * kLd + (lane >> 5);
+        const float *pb = sB + (wc * 32 + (lane & 31)) * kLd + (lane >> 5);
+#pragma unroll
+        for (int k = 0; k < kKT; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col = item0 + wc * 32 + (lane & 31);
+    if (col < n_items) {
+        const float b = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = slot0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < n_slots) scores[(size_t)row * n_items + col] = acc[r] + b;
+        }
     }
 }
 
@@ -213,10 +300,17 @@ int rfm_predict_host(const rfm_model_view *hm, int64_t n_pairs, const float *pai
     return rc;
 }
 
+static int padded_k(const rfm_model_view *m) {
+    const int k = m->has_item_features ? 2 * m->n_factors : m->n_factors;
+    return (k + kKT - 1) / kKT * kKT;
+}
+
+// workspace: scores [chunk, I] | veff [I, Kp] | bias [I] | ueff [chunk, Kp]
 size_t rfm_recommend_workspace_bytes(const rfm_model_view *m, int64_t n_rec_users, int32_t n_rec) {
     if (check_model(m) != RFM_OK || n_rec_users < 0 || n_rec < 1) return 0;
-    const long long chunk = n_rec_users < kRecommendChunk ? (n_rec_users > 0 ? n_rec_users : 1) : kRecommendChunk;
-    return sizeof(float) * (size_t)chunk * (size_t)m->n_items;
+    const size_t chunk = (size_t)(n_rec_users < kRecommendChunk ? (n_rec_users > 0 ? n_rec_users : 1) : kRecommendChunk);
+    const size_t kp = (size_t)padded_k(m), I = (size_t)m->n_items;
+    return sizeof(float) * (chunk * I + I * kp + I + chunk * kp) + 1024;
 }
 
 int rfm_recommend_device(const rfm_model_view *m, int64_t n_users, const float *users, const int64_t *csr_off,
@@ -229,13 +323,20 @@ int rfm_recommend_device(const rfm_model_view *m, int64_t n_users, const float *
     if (!users || !rec || (filter_previous && (!csr_off || !csr_items))) return RFM_ERR_BAD_ARG;
     if (!workspace || workspace_bytes < rfm_recommend_workspace_bytes(m, n_users, n_rec)) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
-    float *scores = (float *)workspace;
     const long long chunk = n_users < kRecommendChunk ? n_users : kRecommendChunk;
-    int gx = (m->n_items * kGroup + 255) / 256;
-    if (gx > 64) gx = 64;
+    const int kp = padded_k(m);
+    const size_t I = (size_t)m->n_items;
+    auto up256 = [](size_t x) { return (x + 63) & ~(size_t)63; };                 // sub-buffers on 256-byte boundaries
+    float *scores = (float *)workspace;
+    float *veff = scores + up256((size_t)chunk * I);
+    float *bias = veff + up256(I * kp);
+    float *ueff = bias + up256(I);
+    build_veff_kernel<<<dim3(512), dim3(256), 0, stream>>>(*m, kp, veff, bias);
     for (long long u0 = 0; u0 < n_users; u0 += chunk) {
         const long long nu = (n_users - u0) < chunk ? (n_users - u0) : chunk;
-        user_scores_kernel<<<dim3(gx, (unsigned)nu), dim3(256), 0, stream>>>(*m, users, u0, scores);
+        build_ueff_kernel<<<dim3(64), dim3(256), 0, stream>>>(*m, users, u0, (int)nu, kp, ueff);
+        scores_mfma_kernel<<<dim3((unsigned)((I + 63) / 64), (unsigned)((nu + 63) / 64)), dim3(256), 0, stream>>>(
+            ueff, veff, bias, (int)nu, m->n_items, kp, scores);
         topn_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, m->n_items, csr_off, csr_items, filter_previous,
                                                                    n_rec, scores, rec);
     }
