@@ -325,8 +325,10 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         mt[624] = 624;
         RFM_HIP(hipMemcpyAsync(ws.mt_state, mt.data(), 625 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
-    degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, cfg->n_users,
-                                                                                      cfg->n_items, ws.error_flags);
+    // (skipped when the caller vouches for a cached plan: the lists were checked when it was built)
+    if (cfg->plan_token <= 0)
+        degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, cfg->n_users,
+                                                                                          cfg->n_items, ws.error_flags);
 
     // ---- plan, part 1 (segments kernel): user segments.  A user of degree d is cut into ceil(d / 32) near-equal runs of
     //      consecutive CSR positions; descriptors {user, first position, length} are built on the host from the offsets.
@@ -582,12 +584,17 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     std::vector<unsigned long long> h_draws(E);
     std::vector<unsigned int> h_nonfinite(E);
     unsigned int h_err[4] = {0, 0, 0, 0};
-    RFM_HIP(hipMemcpyAsync(h_ll.data(), ws.ll, sizeof(double) * E, hipMemcpyDeviceToHost, stream));
-    RFM_HIP(hipMemcpyAsync(h_draws.data(), ws.draws, sizeof(unsigned long long) * E, hipMemcpyDeviceToHost, stream));
-    RFM_HIP(hipMemcpyAsync(h_sumsq.data(), ws.sumsq, sizeof(double) * 6 * E, hipMemcpyDeviceToHost, stream));
-    RFM_HIP(hipMemcpyAsync(h_nonfinite.data(), ws.nonfinite, sizeof(unsigned int) * E, hipMemcpyDeviceToHost, stream));
-    RFM_HIP(hipMemcpyAsync(h_err, ws.error_flags, sizeof(h_err), hipMemcpyDeviceToHost, stream));
+    // ll | draws | sumsq | nonfinite | error_flags are laid out back to back: one copy, one synchronisation
+    const size_t res_bytes = (size_t)((const char *)(ws.error_flags + 4) - (const char *)ws.ll);
+    std::vector<char> h_res(res_bytes);
+    RFM_HIP(hipMemcpyAsync(h_res.data(), ws.ll, res_bytes, hipMemcpyDeviceToHost, stream));
     RFM_HIP(hipStreamSynchronize(stream));
+    auto at = [&](const void *dev) { return h_res.data() + ((const char *)dev - (const char *)ws.ll); };
+    memcpy(h_ll.data(), at(ws.ll), sizeof(double) * E);
+    memcpy(h_draws.data(), at(ws.draws), sizeof(unsigned long long) * E);
+    memcpy(h_sumsq.data(), at(ws.sumsq), sizeof(double) * 6 * E);
+    memcpy(h_nonfinite.data(), at(ws.nonfinite), sizeof(unsigned int) * E);
+    memcpy(h_err, at(ws.error_flags), sizeof(h_err));
 
     int status = RFM_OK;
     int epochs_done = E, bad_array = -1;
