@@ -211,8 +211,8 @@ def c2_problem():
 
 def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
     """BASELINE config 2 at FULL size, default (full-chip) concurrency: two epochs of Hogwild on the GPU against two
-    epochs of the sequential CPU oracle on the same counter-based draws and visiting order.  Norms and per-epoch
-    log-likelihood within 2 %, element-wise correlation of the learned factors > 0.98."""
+    epochs of the sequential CPU oracle on the same counter-based draws and visiting order.  Norms within 2 %,
+    element-wise correlation of the learned factors > 0.98, log-likelihood as stated below."""
     from rankfm_amd import synthetic
     from rankfm_amd.engine import DeviceSession
     U, I, N, F, pairs, csr = c2_problem
@@ -223,7 +223,10 @@ def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
     rep = sess.run(epochs=2)
     g = sess.weights_to_host()
     o, out = _oracle_in_engine_order(oracle, (pairs, csr, sw, x_uf, x_if, None), w, 1, 2, 1492)
-    _assert_statistical_parity(g, rep, o, out)
+    # log-likelihood: 2.5 % in the first epoch (measured +1.96 %: the 64 hottest items are trained through per-workgroup LDS
+    # accumulators and damped accordingly, which costs them a little progress early on), 1.5 % in the second (measured +1.1 %)
+    _assert_statistical_parity(g, rep, o, out, ll_tol=0.025)
+    np.testing.assert_allclose(rep["log_likelihood"][1:], out["ll"][1:], rtol=0.015)
 
 
 @pytest.mark.parametrize("damping", [-1.0, 1e9])
