@@ -124,15 +124,6 @@ __global__ void item_count_kernel(const int32_t *__restrict__ interactions, long
         atomicAdd(count + interactions[2 * r + 1], 1);
 }
 
-// in place: int32 count -> float scale = min(1, cap / count)
-__global__ void item_scale_kernel(int *count, int n_items, float cap) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_items) {
-        const int c = count[i];
-        reinterpret_cast<float *>(count)[i] = c > 0 ? fminf(1.0f, cap / (float)c) : 1.0f;
-    }
-}
-
 // sample weights re-ordered to CSR positions: row r = (u, i) takes the first free slot among the positions of user u that
 // hold item i (duplicates of a pair occupy consecutive positions).  `sw_csr` is pre-filled with the sentinel 0xFFFFFFFF.
 __global__ void sw_to_csr_kernel(const int32_t *__restrict__ interactions, const float *__restrict__ sw, long long n,
@@ -338,18 +329,14 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     int64_t n_segments = have_plan ? (cfg->plan_token & (((int64_t)1 << 40) - 1)) : 0;
     int n_hot = have_plan ? (int)(cfg->plan_token >> 40) : 0;
     const bool build_plan = !serial && cfg->plan_token <= 0;
+    std::vector<int64_t> off;
     if (use_segments && build_plan) {
-        std::vector<int64_t> off((size_t)cfg->n_users + 1);
+        off.resize((size_t)cfg->n_users + 1);
         RFM_HIP(hipMemcpyAsync(off.data(), b->csr_offsets, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost, stream));
         RFM_HIP(hipStreamSynchronize(stream));
         if (off[cfg->n_users] != N) use_segments = false;            // lists hold more than this call's interactions
     }
     if (use_segments && build_plan) {
-        const std::vector<int64_t> off = [&]() {
-            std::vector<int64_t> o((size_t)cfg->n_users + 1);
-            hipMemcpy(o.data(), b->csr_offsets, sizeof(int64_t) * o.size(), hipMemcpyDeviceToHost);
-            return o;
-        }();
         std::vector<int4> desc;
         desc.reserve(max_segments(N, cfg->n_users));
         for (int u = 0; u < cfg->n_users; ++u) {
@@ -617,7 +604,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             }
             if (timing) {
                 float ms = 0.0f;
-                hipEventElapsedTime(&ms, ev[2 * e], ev[2 * e + 1]);
+                (void)hipEventElapsedTime(&ms, ev[2 * e], ev[2 * e + 1]);
                 rep->sgd_kernel_ms[e] = ms;
             }
         }
@@ -628,7 +615,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40)) : kRowsPlan);
     }
     if (timing)
-        for (auto &e : ev) hipEventDestroy(e);
+        for (auto &e : ev) (void)hipEventDestroy(e);
     return status;
 }
 
@@ -668,7 +655,7 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         {nullptr, &d.workspace, ws_bytes, false},
     };
     std::vector<void *> allocated;
-    auto cleanup = [&]() { for (void *p : allocated) hipFree(p); };
+    auto cleanup = [&]() { for (void *p : allocated) (void)hipFree(p); };
     for (Item &it : items) {
         if (it.bytes == 0 && it.dst != (void **)&d.csr_items && it.dst != (void **)&d.interactions &&
             it.dst != (void **)&d.sample_weight) { *it.dst = nullptr; continue; }

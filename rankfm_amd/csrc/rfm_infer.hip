@@ -226,8 +226,6 @@ __global__ void __launch_bounds__(256) topn_kernel(const float *__restrict__ use
     }
 }
 
-static thread_local char g_infer_err[256];
-
 static int check_model(const rfm_model_view *m) {
     if (!m || m->n_users < 1 || m->n_items < 1 || m->n_factors < 1 || m->n_user_features < 1 || m->n_item_features < 1)
         return RFM_ERR_BAD_ARG;
@@ -258,7 +256,7 @@ static int upload_model(const rfm_model_view *h, rfm_model_view *d, void *allocs
 
 static void free_all(void **p, int n) {
     for (int k = 0; k < n; ++k)
-        if (p[k]) hipFree(p[k]);
+        if (p[k]) (void)hipFree(p[k]);
 }
 
 constexpr long long kRecommendChunk = 1024;   // users scored per pass (workspace = chunk * n_items floats)
