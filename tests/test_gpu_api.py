@@ -160,8 +160,9 @@ def test_predict_and_recommend_match_oracle_at_scale(oracle):
     users = rng.integers(0, U, 64).astype(np.float32)
     users[5] = np.nan
     for flt in (False, True):
-        rec = _recommend(users, csr, 10, flt, *args)
-        ro = oracle.recommend(users, csr.offsets, csr.items, 10, flt, *args)
-        assert np.isnan(rec[5]).all() and np.isnan(ro[5]).all()
-        same = rec[~np.isnan(users)] == ro[~np.isnan(users)]
-        assert same.mean() > 0.995          # identical up to fp32 near-ties in the ranking
+        for n_rec in (10, 25):              # one-pass top-n (<= 16) and the multi-pass kernel
+            rec = _recommend(users, csr, n_rec, flt, *args)
+            ro = oracle.recommend(users, csr.offsets, csr.items, n_rec, flt, *args)
+            assert np.isnan(rec[5]).all() and np.isnan(ro[5]).all()
+            same = rec[~np.isnan(users)] == ro[~np.isnan(users)]
+            assert same.mean() > 0.995      # identical up to fp32 near-ties in the ranking
