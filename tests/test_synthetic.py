@@ -45,3 +45,43 @@ def test_configs_match_baseline_json():
     c2 = synthetic.CONFIGS["C2"]
     assert (c2["n_users"], c2["n_items"], c2["n_interactions"], c2["factors"], c2["loss"]) == (100_000, 50_000, 5_000_000, 64, "bpr")
     assert "100k users" in base["configs"][1] and "5M interactions" in base["configs"][1] and "factors=64" in base["configs"][1]
+
+
+def test_order_mirror_matches_the_c_spec(tmp_path):
+    """rankfm_amd/order.py (numpy) must be the same function as include/rfm_rng.h (C, compiled into the kernels and the oracle):
+    compile a probe against the header and compare epoch keys, permutations over many domain sizes, and a full epoch order"""
+    import os
+    import subprocess
+    from conftest import ROOT
+    from rankfm_amd import order
+    src = tmp_path / "probe.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "rfm_rng.h"
+int main(void) {
+    const uint32_t ek = rfm_epoch_key(77, 3);
+    printf("%u\n", ek);
+    for (uint32_t n = 1; n < 70; ++n) for (uint32_t p = 0; p < n; ++p) printf("%u ", rfm_perm(p, n, rfm_perm_bits(n), ek ^ n));
+    printf("\n");
+    for (uint32_t p = 0; p < 5000; ++p) printf("%u ", rfm_perm(p, 5000, rfm_perm_bits(5000), ek));
+    printf("\n%u %u %u\n", rfm_row_key(ek, 12345), rfm_draw(rfm_row_key(ek, 12345), 7), rfm_draw_to_item(0xDEADBEEFu, 50000));
+    return 0;
+}''')
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    ek = order.epoch_key(77, 3)
+    assert ek == int(out[0])
+    got = np.concatenate([order.perm(np.arange(n), n, order.perm_bits(n), ek ^ n) for n in range(1, 70)])
+    assert np.array_equal(got, np.array(out[1].split(), dtype=np.int64))
+    full = order.perm(np.arange(5000), 5000, order.perm_bits(5000), ek)
+    assert np.array_equal(full, np.array(out[2].split(), dtype=np.int64)) and sorted(full.tolist()) == list(range(5000))
+    assert int((0xDEADBEEF * 50000) >> 32) == int(out[3].split()[2])
+    # a whole epoch of the segments kernel's order is a permutation of the CSR positions, user runs of <= 32 rows
+    pairs, csr = synthetic.make_interactions(300, 200, 12000, seed=1)
+    pos = order.epoch_positions(csr.offsets, 5, 0)
+    assert sorted(pos.tolist()) == list(range(12000))
+    users = np.repeat(np.arange(300), np.diff(csr.offsets))[pos]
+    runs = np.diff(np.flatnonzero(np.concatenate([[True], users[1:] != users[:-1], [True]])))
+    assert runs.max() <= order.SEGMENT_ROWS
+    assert not np.array_equal(pos, order.epoch_positions(csr.offsets, 5, 1))
