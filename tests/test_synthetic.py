@@ -81,7 +81,7 @@ int main(void) {
     pairs, csr = synthetic.make_interactions(300, 200, 12000, seed=1)
     pos = order.epoch_positions(csr.offsets, 5, 0)
     assert sorted(pos.tolist()) == list(range(12000))
-    users = np.repeat(np.arange(300), np.diff(csr.offsets))[pos]
-    runs = np.diff(np.flatnonzero(np.concatenate([[True], users[1:] != users[:-1], [True]])))
-    assert runs.max() <= order.SEGMENT_ROWS
+    seg_user, seg_begin, seg_len = order.segments(csr.offsets)
+    assert seg_len.max() <= order.SEGMENT_ROWS and seg_len.min() >= 1 and seg_len.sum() == 12000
+    assert np.array_equal(np.bincount(seg_user, weights=seg_len, minlength=300).astype(np.int64), np.diff(csr.offsets))
     assert not np.array_equal(pos, order.epoch_positions(csr.offsets, 5, 1))
