@@ -399,7 +399,12 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // ---- launch geometry.  unit of work = one interaction (rows kernel) or one user segment (segments kernel)
     const int64_t units = use_segments ? n_segments : N;
     const int groups_per_wave = serial ? 1 : 64 / shape->group;
-    const int waves_per_block = serial ? 1 : (use_segments && (feat || use_hot) ? 16 : 4);      // see sgd_segments_kernel
+    // feature instantiation: the largest workgroup (<= 16 wavefronts) whose table replica + staging area fit in LDS
+    int feat_waves = 16;
+    if (use_segments && feat)
+        while (feat_waves > 1 && feat_lds_bytes(cfg->n_user_features, cfg->n_item_features, cfg->n_factors,
+                                                feat_waves * 64 / shape->group) > kLdsBytes) feat_waves /= 2;
+    const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : (use_hot ? 16 : 4));   // see sgd_segments_kernel
     int grid = 1;
     int64_t max_groups = 0;
     int64_t units_per_launch = units > 0 ? units : 1;
@@ -505,6 +510,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
         a.feat_snapshot = ws.feat_snapshot;
         a.feat_merge = 1.0f / (float)grid;
+        a.block_threads = waves_per_block * 64;
         // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
         a.eta = cfg->learning_schedule == RFM_SCHEDULE_CONSTANT
                     ? cfg->learning_rate

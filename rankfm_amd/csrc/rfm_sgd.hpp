@@ -75,9 +75,18 @@ struct SgdArgs {
     // the right merge while the tables forget faster than a window lasts (DESIGN.md "feature tables"): sequential SGD
     // itself only remembers the last ~1/(2*beta*eta) rows, so any one replica is a fair sample of it, noise level included,
     // whereas the average of K replicas has 1/sqrt(K) of the reference's noise and visibly smaller tables.
+    //
+    // A replica is NOT updated with LDS atomics: ds_add_f32 retires ~3 clocks per active lane on gfx950 whatever the
+    // addresses (tools/microbench/lds_atomic.hip: 193 clk per 64-lane instruction against 8 clk for a plain read + write),
+    // and with them the feature kernel spent 85 % of its time in the LDS atomic unit.  Instead the workgroup steps in
+    // lock-step: every row group handles one interaction against the replica as it stands, STAGES the row's feature steps
+    // (g, d_outer, the updated v_u and v_i - v_j, x_uf[u], x_if[i] - x_if[j]) in LDS, and after a barrier each table row is
+    // walked by one wavefront that applies the staged steps of all groups in group order with plain reads and writes --
+    // the reference's own update formula, row by row, on values that are stale by at most one workgroup step.
     const float *__restrict__ feat_snapshot;
     float feat_merge;
     int32_t feat_select_wg;
+    int32_t block_threads;                      // workgroup size of the feature instantiation (host: LDS budget)
     // hot positive items (segments kernel, HOT instantiation): pos_scale[i] >= 2 encodes slot = int(v / 2) - 1 and
     // scale = v - 2 (slot + 1).  A workgroup accumulates its updates of slot s in LDS and publishes them with one set of
     // atomics every hot_period[s] touches (DESIGN.md "hot rows").
@@ -85,6 +94,12 @@ struct SgdArgs {
     const int32_t *__restrict__ hot_period;     // [n_hot] touches per workgroup between publications
     int32_t n_hot;
 };
+
+// LDS of the feature instantiation: the table replica + the staging area of `groups` row groups
+inline size_t feat_lds_bytes(int n_uf, int n_if, int n_factors, int groups) {
+    return sizeof(float) * ((size_t)(n_uf + n_if) * n_factors + n_if + (size_t)groups * (3 + 2 * (size_t)n_factors + n_uf + n_if));
+}
+constexpr size_t kLdsBytes = 160 * 1024;        // per workgroup on gfx950
 
 constexpr float kMargin = 1.0f;                 // rankfm/_rankfm.pyx:149
 constexpr uint32_t kMaxAttempts = 1u << 22;     // safety net; the host rejects saturated users up front
@@ -242,6 +257,10 @@ struct RowStep {
     const int F;
     typedef typename TablePtr<LDSF>::type TabPtr;
     TabPtr t_v_uf, t_v_if, t_w_if;   // feature tables: global memory, or the workgroup's LDS replica (LDSF)
+    // staging area of the workgroup's feature steps (LDSF): [NG,3] {g, d_outer, active} | [NG,F] updated v_u |
+    // [NG,F] updated v_i - v_j | [NG,P] x_uf[u] | [NG,Q] x_if[i] - x_if[j];  wg_group = this group's row in them
+    lds_float *st_row = nullptr, *st_nvu = nullptr, *st_dij = nullptr, *st_xu = nullptr, *st_dx = nullptr;
+    int wg_group = 0;
     lds_float *hot_acc = nullptr;    // LDS [n_hot, F] pending factor deltas,  [n_hot] pending bias deltas, [n_hot] touch counters
     lds_float *hot_accw = nullptr;
     lds_int *hot_cnt = nullptr;
@@ -311,6 +330,24 @@ struct RowStep {
         } else {
             for (int q = sub; q < va.n; q += G) fn(q, va.mem[q], vb.mem[q]);
         }
+    }
+
+    // dst[q] = va[q] - vb[q] (vb may be null) for the entries this lane owns
+    __device__ __forceinline__ void xstage(const XV &va, const XV *vb, lds_float *dst) const {
+        if (va.n <= G * MAXR) {
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k)
+                if (sub + G * k < va.n) dst[sub + G * k] = vb ? va.r[k] - vb->r[k] : va.r[k];
+        } else {
+            for (int q = sub; q < va.n; q += G) dst[q] = vb ? va.mem[q] - vb->mem[q] : va.mem[q];
+        }
+    }
+
+    // a group without an interaction in this workgroup step contributes nothing to the batch
+    __device__ __forceinline__ void stage_idle() const {
+        if (sub == 0) st_row[3 * wg_group + 2] = 0.0f;
+        if (a.has_uf) for (int q = sub; q < a.n_uf; q += G) st_xu[wg_group * a.n_uf + q] = 0.0f;
+        if (a.has_if) for (int q = sub; q < a.n_if; q += G) st_dx[wg_group * a.n_if + q] = 0.0f;
     }
 
     // acc[f] = sum_r x[r] * table[r, f]   (feature projection into factor space, this lane's dwords)
@@ -503,7 +540,7 @@ struct RowStep {
         }
 
         // item-feature weights (:283-286): every q shrinks, lanes split the q range
-        if constexpr (FEAT) {
+        if constexpr (FEAT && !LDSF) {
             if (a.has_if) {
                 xown2(xi, xj, [&](int q, float xa, float xb) {
                     const float w = t_w_if[q];
@@ -557,7 +594,23 @@ struct RowStep {
             }
         }
 
-        if constexpr (FEAT) {
+        if constexpr (FEAT && LDSF) {
+            // stage the row's feature steps; the workgroup applies them after its barrier (apply_feature_batch)
+            if (sub == 0) {
+                st_row[3 * wg_group] = g;
+                st_row[3 * wg_group + 1] = d_outer;
+                st_row[3 * wg_group + 2] = 1.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                if (!dword_ok(k)) continue;
+                st_nvu[wg_group * F + dword_f(k)] = nvu[k];
+                st_dij[wg_group * F + dword_f(k)] = dij[k];
+            }
+            if (a.has_uf) xstage(xu, nullptr, st_xu + wg_group * a.n_uf);
+            if (a.has_if) xstage(xi, &xj, st_dx + wg_group * a.n_if);
+        }
+        if constexpr (FEAT && !LDSF) {
             // user-feature factors (:313-318): rows p with x_uf[u,p] != 0, using the UPDATED v_i[i]-v_i[j]
             if (a.has_uf) {
                 xfor(xu, [&](int p, float xp) {
@@ -592,6 +645,42 @@ struct RowStep {
         }
     }
 };
+
+// The workgroup's staged feature steps applied to its LDS replica (see SgdArgs::feat_snapshot).  One wavefront per table
+// row, lanes over the factors; the staged coefficient of (group, row) is wavefront-uniform, so rows a group does not
+// touch cost one broadcast read.  Each touch is the reference's formula (rankfm/_rankfm.pyx:283-286, :313-326),
+//   t += eta * (g * (d_outer * (x * vec_f)) - reg_b * t),
+// applied in group order.
+__device__ __forceinline__ void apply_feature_batch(const SgdArgs &a, lds_float *t_v_uf, lds_float *t_v_if, lds_float *t_w_if,
+                                                    const lds_float *st_row, const lds_float *st_nvu, const lds_float *st_dij,
+                                                    const lds_float *st_xu, const lds_float *st_dx, int n_groups) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int F = a.n_factors;
+    const float eta_f = a.eta, reg_b = a.reg_b;
+    auto rows = [&](lds_float *table, int n_rows, const lds_float *coef, const lds_float *vec) {
+        for (int r = wave; r < n_rows; r += n_waves)
+            for (int f = lane; f < F; f += 64) {
+                float t = table[r * F + f];
+                for (int gi = 0; gi < n_groups; ++gi) {
+                    const float x = coef[gi * n_rows + r];
+                    if (x == 0.0f) continue;
+                    t += eta_f * (st_row[3 * gi] * (st_row[3 * gi + 1] * (x * vec[gi * F + f])) - reg_b * t);
+                }
+                table[r * F + f] = t;
+            }
+    };
+    if (a.has_uf) rows(t_v_uf, a.n_uf, st_xu, st_dij);
+    if (a.has_if) {
+        rows(t_v_if, a.n_if, st_dx, st_nvu);
+        for (int q = threadIdx.x; q < a.n_if; q += blockDim.x) {       // every q shrinks with every row (:283-286)
+            float w = t_w_if[q];
+            for (int gi = 0; gi < n_groups; ++gi)
+                if (st_row[3 * gi + 2] != 0.0f)
+                    w += eta_f * (st_row[3 * gi] * (st_row[3 * gi + 1] * st_dx[gi * a.n_if + q]) - reg_b * w);
+            t_w_if[q] = w;
+        }
+    }
+}
 
 // wavefront reduction of the log-likelihood / draw counters, one atomic each per wavefront
 __device__ __forceinline__ void flush_counters(const SgdArgs &a, double ll_acc, unsigned draw_acc) {
@@ -674,6 +763,15 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         if constexpr (FEAT) return Step(a, sub, lds, lds + a.n_uf * F, lds + (a.n_uf + a.n_if) * F);
         else return Step(a, sub, a.v_uf, a.v_if, a.w_if);
     }();
+    const int wg_groups = blockDim.x / G;
+    if constexpr (FEAT) {
+        step.wg_group = threadIdx.x / G;
+        step.st_row = lds + n_tab;
+        step.st_nvu = step.st_row + 3 * wg_groups;
+        step.st_dij = step.st_nvu + wg_groups * F;
+        step.st_xu = step.st_dij + wg_groups * F;
+        step.st_dx = step.st_xu + wg_groups * a.n_uf;
+    }
     if constexpr (HOT) {
         // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] touch counters
         const int n_acc = a.n_hot * (F + 2);
@@ -697,7 +795,10 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
 
-    while (__any(active)) {
+    for (;;) {
+        // with features the workgroup advances in lock-step (two barriers per step: this one and the one before the batch)
+        if constexpr (FEAT) { if (!__syncthreads_or(active)) break; }
+        else { if (!__any(active)) break; }
         if (active && !have) {
             const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
             const int4 d = a.seg_desc[seg];
@@ -727,6 +828,13 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
                 sp += stride;
                 active = sp < a.pos_end;
             }
+        } else if constexpr (FEAT) {
+            step.stage_idle();
+        }
+        if constexpr (FEAT) {
+            __syncthreads();
+            apply_feature_batch(a, step.t_v_uf, step.t_v_if, step.t_w_if, step.st_row, step.st_nvu, step.st_dij, step.st_xu,
+                                step.st_dx, wg_groups);
         }
     }
     if constexpr (HOT) {          // publish whatever is still pending
