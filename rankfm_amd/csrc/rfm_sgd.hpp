@@ -95,9 +95,9 @@ struct SgdArgs {
     int32_t n_hot;
 };
 
-// LDS of the feature instantiation: the table replica + the staging area of `groups` row groups
+// LDS of the feature instantiation: the table replica + two staging areas of `groups` row groups
 inline size_t feat_lds_bytes(int n_uf, int n_if, int n_factors, int groups) {
-    return sizeof(float) * ((size_t)(n_uf + n_if) * n_factors + n_if + (size_t)groups * (3 + 2 * (size_t)n_factors + n_uf + n_if));
+    return sizeof(float) * ((size_t)(n_uf + n_if) * n_factors + n_if + 2 * (size_t)groups * (3 + 2 * (size_t)n_factors + n_uf + n_if));
 }
 constexpr size_t kLdsBytes = 160 * 1024;        // per workgroup on gfx950
 
@@ -646,38 +646,79 @@ struct RowStep {
     }
 };
 
-// The workgroup's staged feature steps applied to its LDS replica (see SgdArgs::feat_snapshot).  One wavefront per table
-// row, lanes over the factors; the staged coefficient of (group, row) is wavefront-uniform, so rows a group does not
-// touch cost one broadcast read.  Each touch is the reference's formula (rankfm/_rankfm.pyx:283-286, :313-326),
-//   t += eta * (g * (d_outer * (x * vec_f)) - reg_b * t),
-// applied in group order.
+// The workgroup's staged feature steps applied to its LDS replica (see SgdArgs::feat_snapshot).  For one table (rows r,
+// coefficient x[g,r] = x_uf[u_g,r] or x_if[i_g,r] - x_if[j_g,r], vector vec[g,:] = updated v_i - v_j or updated v_u of
+// group g) the batch of the reference's row updates (rankfm/_rankfm.pyx:313-326)
+//     T[r,:] += eta * (g_g * d_outer_g * x[g,r] * vec[g,:] - reg_b * T[r,:])          for every g with x[g,r] != 0
+// applied in group order is, with keep = 1 - eta * reg_b, n = touches(r) and rank(g,r) = touching groups before g,
+//     T[r,:]  = keep^n * ( T[r,:] + eta * sum_g c[g,r] * vec[g,:] ),   c[g,r] = g_g * d_outer_g * x[g,r] * keep^-(rank(g,r)+1)
+// i.e. a [rows x groups] x [groups x F] product: one 32 x 32 tile per wavefront on the matrix cores
+// (v_mfma_f32_32x32x2_f32 is exact fp32), operands read straight from the staging area.  With one group in flight this is
+// the reference's update to rounding.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ void apply_feature_batch(const SgdArgs &a, lds_float *t_v_uf, lds_float *t_v_if, lds_float *t_w_if,
                                                     const lds_float *st_row, const lds_float *st_nvu, const lds_float *st_dij,
                                                     const lds_float *st_xu, const lds_float *st_dx, int n_groups) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int F = a.n_factors;
     const float eta_f = a.eta, reg_b = a.reg_b;
-    auto rows = [&](lds_float *table, int n_rows, const lds_float *coef, const lds_float *vec) {
-        for (int r = wave; r < n_rows; r += n_waves)
-            for (int f = lane; f < F; f += 64) {
-                float t = table[r * F + f];
-                for (int gi = 0; gi < n_groups; ++gi) {
-                    const float x = coef[gi * n_rows + r];
-                    if (x == 0.0f) continue;
-                    t += eta_f * (st_row[3 * gi] * (st_row[3 * gi + 1] * (x * vec[gi * F + f])) - reg_b * t);
+    const float keep = 1.0f - eta_f * reg_b;
+    const float inv1 = 1.0f / keep, inv2 = inv1 * inv1, inv3 = inv2 * inv1, inv4 = inv2 * inv2;
+    // 16 x 16 output tiles (v_mfma_f32_16x16x4_f32, four groups per step): 16 tiles for 32 + 32 rows x 64 factors, one per
+    // wavefront of the 1024-thread workgroup
+    const int f_tiles = (F + 15) / 16;
+    const int uf_tiles = a.has_uf ? ((a.n_uf + 15) / 16) * f_tiles : 0;
+    const int if_tiles = a.has_if ? ((a.n_if + 15) / 16) * f_tiles : 0;
+    // w_if (:283-286) is a third table with one column: coefficient x_if[i] - x_if[j] as for v_if, "vector" 1, but EVERY q
+    // is touched (shrinks) by every row
+    const int w_tiles = a.has_if ? (a.n_if + 15) / 16 : 0;
+    for (int tile = wave; tile < uf_tiles + if_tiles + w_tiles; tile += n_waves) {
+        const bool uf = tile < uf_tiles, bias = tile >= uf_tiles + if_tiles;
+        const int tt = uf ? tile : (bias ? tile - uf_tiles - if_tiles : tile - uf_tiles);
+        lds_float *table = uf ? t_v_uf : (bias ? t_w_if : t_v_if);
+        const lds_float *coef = uf ? st_xu : st_dx, *vec = uf ? st_dij : st_nvu;
+        const int n_rows = uf ? a.n_uf : a.n_if;
+        const int width = bias ? 1 : F;
+        const int r0 = bias ? tt * 16 : (tt / f_tiles) * 16, f0 = bias ? 0 : (tt % f_tiles) * 16;
+        // A operand: lane l holds c[g = k0 + (l >> 4)][r = r0 + (l & 15)];  B operand: vec[g = k0 + (l >> 4)][f = f0 + (l & 15)]
+        const int r16 = lane & 15, r = r0 + r16, f = f0 + r16, kk = lane >> 4;
+        f32x4 acc = {0};
+        int touches = 0;
+        float grow = 1.0f;                                  // keep^-(touching groups before this k-step)
+        for (int k0 = 0; k0 < n_groups; k0 += 4) {
+            const int g = k0 + kk;
+            float x = 0.0f, vb = 0.0f;
+            bool touch = false;
+            if (g < n_groups) {
+                if (r < n_rows) {
+                    x = coef[g * n_rows + r];
+                    touch = bias ? st_row[3 * g + 2] != 0.0f : x != 0.0f;
                 }
-                table[r * F + f] = t;
+                if (f < width) vb = bias ? 1.0f : vec[g * F + f];
             }
-    };
-    if (a.has_uf) rows(t_v_uf, a.n_uf, st_xu, st_dij);
-    if (a.has_if) {
-        rows(t_v_if, a.n_if, st_dx, st_nvu);
-        for (int q = threadIdx.x; q < a.n_if; q += blockDim.x) {       // every q shrinks with every row (:283-286)
-            float w = t_w_if[q];
-            for (int gi = 0; gi < n_groups; ++gi)
-                if (st_row[3 * gi + 2] != 0.0f)
-                    w += eta_f * (st_row[3 * gi] * (st_row[3 * gi + 1] * st_dx[gi * a.n_if + q]) - reg_b * w);
-            t_w_if[q] = w;
+            // the four lanes of a row (groups k0 .. k0+3) learn from one ballot which of them touch it
+            const unsigned long long m = __ballot(touch) >> r16;
+            const int b0 = (int)(m & 1), b1 = (int)((m >> 16) & 1), b2 = (int)((m >> 32) & 1), b3 = (int)((m >> 48) & 1);
+            const int before = (kk > 0 ? b0 : 0) + (kk > 1 ? b1 : 0) + (kk > 2 ? b2 : 0), all = b0 + b1 + b2 + b3;
+            float ca = 0.0f;
+            if (touch)
+                ca = st_row[3 * g] * st_row[3 * g + 1] * x * grow * (before == 0 ? inv1 : before == 1 ? inv2 : before == 2 ? inv3 : inv4);
+            grow *= all == 0 ? 1.0f : all == 1 ? inv1 : all == 2 ? inv2 : all == 3 ? inv3 : inv4;
+            touches += all;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca, vb, acc, 0, 0, 0);
+        }
+        float shrink = 1.0f, b = keep;                      // keep ^ touches(r), exact for one touch
+        for (int n = touches; n; n >>= 1) { if (n & 1) shrink *= b; b *= b; }
+        // C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row_l = 4 * kk + reg;
+            const float sh = __shfl(shrink, row_l);
+            if (r0 + row_l < n_rows && f < width) {
+                lds_float *t = table + (r0 + row_l) * width + f;
+                *t = sh * (*t + eta_f * acc[reg]);
+            }
         }
     }
 }
@@ -764,13 +805,23 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         else return Step(a, sub, a.v_uf, a.v_if, a.w_if);
     }();
     const int wg_groups = blockDim.x / G;
-    if constexpr (FEAT) {
-        step.wg_group = threadIdx.x / G;
-        step.st_row = lds + n_tab;
+    // two staging areas, used alternately: while some wavefronts still apply step s from one, the others stage step s+1 in
+    // the other -- one barrier per step (see the loop)
+    const int n_stage = wg_groups * (3 + 2 * F + a.n_uf + a.n_if);
+    auto set_stage = [&](int buf) {
+        step.st_row = lds + n_tab + buf * n_stage;
         step.st_nvu = step.st_row + 3 * wg_groups;
         step.st_dij = step.st_nvu + wg_groups * F;
         step.st_xu = step.st_dij + wg_groups * F;
         step.st_dx = step.st_xu + wg_groups * a.n_uf;
+    };
+    int stage_buf = 0;
+    if constexpr (FEAT) {
+        step.wg_group = threadIdx.x / G;
+        set_stage(0);
+        // idle groups enter the batch product with coefficient 0: their staged vectors must at least be finite
+        for (int k = threadIdx.x; k < 2 * n_stage; k += blockDim.x) lds_tables[n_tab + k] = 0.0f;
+        __syncthreads();
     }
     if constexpr (HOT) {
         // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] touch counters
@@ -796,9 +847,8 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
 
     for (;;) {
-        // with features the workgroup advances in lock-step (two barriers per step: this one and the one before the batch)
-        if constexpr (FEAT) { if (!__syncthreads_or(active)) break; }
-        else { if (!__any(active)) break; }
+        if constexpr (!FEAT) { if (!__any(active)) break; }
+        const bool works = active;
         if (active && !have) {
             const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
             const int4 d = a.seg_desc[seg];
@@ -832,9 +882,15 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
             step.stage_idle();
         }
         if constexpr (FEAT) {
-            __syncthreads();
+            // With features the workgroup advances in lock-step, one barrier per step: behind it every group's row of this
+            // step is staged, and every wavefront has finished applying the previous step (it did so before it started
+            // this one), so the other staging area is free again.  The batch is applied while faster wavefronts already
+            // work on their next rows -- they may read a table row half-way through its update, which is Hogwild as usual.
+            if (!__syncthreads_or(works)) break;
             apply_feature_batch(a, step.t_v_uf, step.t_v_if, step.t_w_if, step.st_row, step.st_nvu, step.st_dij, step.st_xu,
                                 step.st_dx, wg_groups);
+            stage_buf ^= 1;
+            set_stage(stage_buf);
         }
     }
     if constexpr (HOT) {          // publish whatever is still pending
