@@ -29,6 +29,10 @@ __global__ void __launch_bounds__(1024) k(float *out, int iters, int stride_rows
             acc += p[row * 64 + lane];
         } else if (MODE == 6) {     // 4 groups on 4 different rows, dword index rotated by group -> distinct banks
             __hip_atomic_fetch_add(p + ((row + (lane >> 4)) & 63) * 64 + ((lane & 15) + 16 * (lane >> 4)), 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (MODE == 8) {     // integer atomic, 64 lanes / 64 dwords
+            atomicAdd((int *)lds + row * 64 + lane, 3);
+        } else if (MODE == 9) {     // integer atomic, 4 groups on the same 16 dwords
+            atomicAdd((int *)lds + row * 64 + (lane & 15), 3);
         } else if (MODE == 7) {     // returning atomic
             acc += __hip_atomic_fetch_add(p + row * 64 + lane, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -61,6 +65,8 @@ int main() {
         run<3>("ds_add_f32 4 groups, 4 rows, same banks", s);
         run<6>("ds_add_f32 4 groups, 4 rows, distinct banks", s);
         run<7>("ds_add_rtn_f32 64 lanes", s);
+        run<8>("ds_add_u32 64 lanes / 64 dwords", s);
+        run<9>("ds_add_u32 4 groups same 16 dwords", s);
         run<4>("plain ds_read + ds_write 64 lanes", s);
         run<5>("plain ds_read 64 lanes", s);
     }
