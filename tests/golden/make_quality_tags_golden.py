@@ -1,0 +1,43 @@
+"""Ranking quality WITH user/item features from the REFERENCE itself (build container only; see make_golden.py for how the
+reference is loaded): factors=20, BPR, 5 epochs on the seeded planted surrogate at half MovieLens-1M size with 8 binary user
+tags and 8 binary item tags that carry signal (rankfm_amd.synthetic.make_planted(n_tags=8)).  Per seed the reference's own
+hit_rate@10 and the Frobenius norms of all six fitted arrays.  Only numbers are stored; the data are regenerated from the seeds."""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "..", "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_loader  # noqa: E402
+from rankfm_amd import synthetic  # noqa: E402
+
+RankFM, _, ev = ref_loader.load_reference()
+LEARNING_RATE = 0.03      # with 8 + 8 dense tags the reference itself diverges at its default 0.1
+PROBLEM = dict(n_users=3000, n_items=2000, mean_degree=100.0, n_tags=8)
+
+
+def frames(d):
+    train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
+    uf = pd.DataFrame(np.column_stack([np.arange(len(d["user_tags"])), d["user_tags"]]))
+    itf = pd.DataFrame(np.column_stack([np.arange(len(d["item_tags"])), d["item_tags"]]))
+    return train, test, uf, itf
+
+
+if __name__ == "__main__":
+    rows = []
+    for seed in (0, 1, 2):
+        d = synthetic.make_planted(seed=seed, **PROBLEM)
+        train, test, uf, itf = frames(d)
+        m = RankFM(factors=20, loss="bpr", learning_rate=LEARNING_RATE)
+        np.random.seed(seed)
+        m.fit(train, user_features=uf, item_features=itf, epochs=5)
+        rows.append([ev.hit_rate(m, test, k=10)] + [np.linalg.norm(getattr(m, k)) for k in ("v_u", "v_i", "w_i", "v_uf", "v_if", "w_if")]
+                    + [len(train)])
+        print(seed, np.round(rows[-1], 4), flush=True)
+    np.savez(os.path.join(HERE, "quality_planted_tags.npz"),
+             columns=np.array(["hit_rate", "norm_v_u", "norm_v_i", "norm_w_i", "norm_v_uf", "norm_v_if", "norm_w_if", "n_train"]),
+             bpr=np.array(rows))
