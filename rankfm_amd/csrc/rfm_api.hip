@@ -162,6 +162,7 @@ struct Workspace {
     unsigned int *error_flags;    // [1] (+pad)
     uint32_t *mt_state;           // [625] (+pad)
     float *multiplier;            // [max_samples + 1]
+    float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: zero between launches
     float *feat_snapshot;         // [(P+Q)*F + Q] feature tables at launch start (LDS-replica merge)
     size_t bytes;
 };
@@ -172,7 +173,7 @@ constexpr int kMaxHot = 64;                      // hot-row accumulator slots pe
 
 static size_t max_segments(int64_t n_rows, int n_users) { return (size_t)n_users + (size_t)(n_rows / kSegmentRows) + 1; }
 
-static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_feat_tab) {
+static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_feat_tab, int n_factors) {
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
@@ -190,6 +191,8 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
     w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
     w.feat_snapshot = (float *)(p + o);          o += align_up(sizeof(float) * n_feat_tab);
+    w.hot_bins_v = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot * (size_t)n_factors);
+    w.hot_bins_w = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot);
     w.bytes = o;
     return w;
 }
@@ -275,7 +278,7 @@ int rfm_fit_supported(const rfm_fit_config *cfg) { return validate(cfg); }
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
-    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_table_floats(cfg)).bytes;
+    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_table_floats(cfg), cfg->n_factors).bytes;
 }
 
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
@@ -288,7 +291,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     if ((rc = device_ok()) != RFM_OK) return rc;
     const int E = cfg->epochs;
     const int64_t N = cfg->n_interactions;
-    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_table_floats(cfg));
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_table_floats(cfg), cfg->n_factors);
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
@@ -465,10 +468,10 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             scale[i] = n > damp_m ? (float)(damp_m / n) : 1.0f;
         }
         std::vector<int32_t> h_item(kMaxHot, 0), h_period(kMaxHot, 1);
-        const double hot_pubs = getenv("RFM_HOT_PUBS") ? atof(getenv("RFM_HOT_PUBS")) : 24.0;   // experiment knob
+        const double hot_pubs = getenv("RFM_HOT_PUBS") ? atof(getenv("RFM_HOT_PUBS")) : 48.0;   // experiment knob
         for (int s = 0; s < (use_hot ? n_hot : 0); ++s) {
             const int i = hot_order[s];
-            // publish about 24 times per epoch and workgroup: ~4 % of the row's updates are pending chip-wide at any time
+            // publish about 48 times per epoch and workgroup: ~2 % of the row's updates are pending chip-wide at any time
             int period = (int)((double)item_count[i] / ((double)grid * hot_pubs) + 0.5);
             if (period < 1) period = 1;
             if (period > 64) period = 64;
@@ -508,6 +511,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.single_group = single_group ? 1 : 0;
         a.max_groups = max_groups;
         a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
+        a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w;
+        a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 2 * grid ? 1 : 0;   // see SgdArgs::hot_bins_v
         a.feat_snapshot = ws.feat_snapshot;
         a.feat_merge = 1.0f / (float)grid;
         a.block_threads = waves_per_block * 64;

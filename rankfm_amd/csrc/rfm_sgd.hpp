@@ -93,7 +93,18 @@ struct SgdArgs {
     const int32_t *__restrict__ hot_item;       // [n_hot] item index of each slot
     const int32_t *__restrict__ hot_period;     // [n_hot] touches per workgroup between publications
     int32_t n_hot;
+    // Publications do not go to the hot rows themselves: memory-side atomics on ONE address retire serially, and 256
+    // workgroups publishing into the same 64 rows cost 0.55 ms of a 3.6 ms epoch (measured by publishing to private
+    // addresses instead).  A workgroup adds its pending sums into bin (workgroup % kHotBins) of these arrays; every
+    // 64-byte line of the bins has an owner workgroup that sweeps it every few rows (exchange with zero over the bins,
+    // one atomic add of the total into v_i / w_i), and hot_reduce_kernel drains what is left when the launch ends.
+    // With few workgroups (fewer than half the lines) there is little contention and a line would wait long for its
+    // sweep: hot_direct = 1 publishes straight into the rows.
+    float *hot_bins_v;                          // [kHotBins, n_hot, F]
+    float *hot_bins_w;                          // [kHotBins, n_hot]
+    int32_t hot_direct;
 };
+constexpr int kHotBins = 16;
 
 // LDS of the feature instantiation: the table replica + two staging areas of `groups` row groups
 inline size_t feat_lds_bytes(int n_uf, int n_if, int n_factors, int groups) {
@@ -261,9 +272,20 @@ struct RowStep {
     // [NG,F] updated v_i - v_j | [NG,P] x_uf[u] | [NG,Q] x_if[i] - x_if[j];  wg_group = this group's row in them
     lds_float *st_row = nullptr, *st_nvu = nullptr, *st_dij = nullptr, *st_xu = nullptr, *st_dx = nullptr;
     int wg_group = 0;
-    lds_float *hot_acc = nullptr;    // LDS [n_hot, F] pending factor deltas,  [n_hot] pending bias deltas, [n_hot] touch counters
-    lds_float *hot_accw = nullptr;
+    // LDS [n_hot, F] pending factor deltas, [n_hot] pending bias deltas, [n_hot] touch counters.  The pending sums are
+    // 32-bit FIXED POINT (units of 2^-24, +-128): ds_add_u32 takes ~5 clocks per wave instruction where ds_add_f32 takes
+    // ~3 clocks per active lane (tools/microbench/lds_atomic.hip), and every cross-lane shuffle of the workgroup queues
+    // behind them in the same LDS pipeline.  A pending sum stays far inside the range (<= 64 touches of steps < 0.3).
+    lds_int *hot_acc = nullptr;
+    lds_int *hot_accw = nullptr;
     lds_int *hot_cnt = nullptr;
+    static constexpr float kHotScale = 16777216.0f, kHotUnit = 1.0f / 16777216.0f;
+    static __device__ __forceinline__ void hot_add(lds_int *p, float v) {
+        __hip_atomic_fetch_add(p, __float2int_rn(v * kHotScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    static __device__ __forceinline__ float hot_take(lds_int *p) {
+        return (float)__hip_atomic_exchange(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * kHotUnit;
+    }
 
     __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_, TabPtr v_uf, TabPtr v_if, TabPtr w_if)
         : a(args), sub(sub_), F(args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
@@ -373,8 +395,8 @@ struct RowStep {
             if (slot >= 0) {      // the workgroup's own pending updates of a hot row are part of its view of the row
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
-                    if (dword_ok(k)) vi[k] += hot_acc[slot * F + dword_f(k)];
-                wi += hot_accw[slot];
+                    if (dword_ok(k)) vi[k] += (float)hot_acc[slot * F + dword_f(k)] * kHotUnit;
+                wi += (float)hot_accw[slot] * kHotUnit;
             }
         }
         float part = 0.0f, scalar = 0.0f;
@@ -534,7 +556,7 @@ struct RowStep {
         if (sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
-            if (HOT && slot >= 0) atomic_add_f32(hot_accw + slot, dwi);
+            if (HOT && slot >= 0) hot_add(hot_accw + slot, dwi);
             else if (!skip_pos) apply_f32<SERIAL>(a.w_i + i, wi, dwi, plain_items);
             apply_f32<SERIAL>(a.w_i + j, wj, dwj, plain_items);
         }
@@ -564,7 +586,7 @@ struct RowStep {
             if (dword_ok(k)) {
                 const int f = dword_f(k);
                 if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u, plain_user);
-                if (HOT && slot >= 0) atomic_add_f32(hot_acc + slot * F + f, d_i);
+                if (HOT && slot >= 0) hot_add(hot_acc + slot * F + f, d_i);
                 else if (!skip_pos) apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i, plain_items);
                 apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
             }
@@ -583,12 +605,14 @@ struct RowStep {
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
-                        const float d = __hip_atomic_exchange(hot_acc + slot * F + dword_f(k), 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (d != 0.0f) atomic_add_f32(a.v_i + (size_t)i * F + dword_f(k), d);
+                        const float d = hot_take(hot_acc + slot * F + dword_f(k));
+                        if (d != 0.0f)
+                            atomic_add_f32(a.hot_direct ? a.v_i + (size_t)i * F + dword_f(k)
+                                                        : a.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * a.n_hot + slot) * F + dword_f(k), d);
                     }
                     if (sub == 0) {
-                        const float d = __hip_atomic_exchange(hot_accw + slot, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (d != 0.0f) atomic_add_f32(a.w_i + i, d);
+                        const float d = hot_take(hot_accw + slot);
+                        if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + i : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + slot, d);
                     }
                 }
             }
@@ -774,6 +798,48 @@ __global__ void __launch_bounds__(256) sgd_rows_kernel(const SgdArgs a) {
     flush_counters(a, ll_acc, draw_acc);
 }
 
+// One 64-byte line of the hot-row bins (see SgdArgs::hot_bins_v), swept by one wavefront: lanes = 4 bins x 16 dwords at a
+// time, exchange with zero, sum over the bins, one atomic add of the total into the hot row.  Lines 0 .. n_hot*LPR-1 are
+// 16-factor pieces of the hot rows (LPR = lines per row), the rest are 16 slots' biases each.
+__device__ __forceinline__ int hot_lines(const SgdArgs &a) { return a.n_hot * ((a.n_factors + 15) / 16) + (a.n_hot + 15) / 16; }
+
+__device__ __forceinline__ void hot_sweep_line(const SgdArgs &a, int line) {
+    const int lane = threadIdx.x & 63, d16 = lane & 15, quad = lane >> 4;
+    const int F = a.n_factors, lpr = (F + 15) / 16;
+    const bool bias = line >= a.n_hot * lpr;
+    float *src, *dst;
+    size_t bin_stride;
+    bool ok;
+    if (!bias) {
+        const int slot = line / lpr, f = (line % lpr) * 16 + d16;
+        ok = f < F;
+        src = a.hot_bins_v + (size_t)slot * F + f;
+        bin_stride = (size_t)a.n_hot * F;
+        dst = a.v_i + (size_t)a.hot_item[slot] * F + f;
+    } else {
+        const int slot = (line - a.n_hot * lpr) * 16 + d16;
+        ok = slot < a.n_hot;
+        src = a.hot_bins_w + slot;
+        bin_stride = (size_t)a.n_hot;
+        dst = a.w_i + a.hot_item[ok ? slot : 0];
+    }
+    float acc = 0.0f;
+    if (ok) {
+#pragma unroll
+        for (int b = 0; b < kHotBins; b += 4)
+            acc += __hip_atomic_exchange(src + (size_t)(b + quad) * bin_stride, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (quad == 0 && ok && acc != 0.0f) atomic_add_f32(dst, acc);
+}
+
+// drains the bins after a launch of the HOT kernel (one wavefront per line)
+static __global__ void __launch_bounds__(256) hot_reduce_kernel(const SgdArgs a) {
+    const int line = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (line < hot_lines(a)) hot_sweep_line(a, line);
+}
+
 // ---------------------------------------------------------------------------------------------
 // segments kernel (production Hogwild): see the header comment.  Each group is a little state machine
 //   [fetch segment + v_u] -> row, row, ... -> [write back v_u delta] -> next segment
@@ -828,8 +894,8 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         const int n_acc = a.n_hot * (F + 2);
         for (int k = threadIdx.x; k < n_acc; k += blockDim.x) lds_tables[k] = 0.0f;
         __syncthreads();
-        step.hot_acc = lds;
-        step.hot_accw = lds + a.n_hot * F;
+        step.hot_acc = (lds_int *)lds;
+        step.hot_accw = (lds_int *)(lds + a.n_hot * F);
         step.hot_cnt = (lds_int *)(lds + a.n_hot * (F + 1));
     }
 
@@ -846,8 +912,15 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
 
-    for (;;) {
+    for (int iter = 0;; ++iter) {
         if constexpr (!FEAT) { if (!__any(active)) break; }
+        if constexpr (HOT) {
+            // bin sweeping duty (see SgdArgs::hot_bins_v): the wavefronts of a workgroup take turns, one turn per row; a turn
+            // sweeps the workgroup's lines (at most two, else the host chose hot_direct)
+            const int n_waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+            if (!a.hot_direct && iter % n_waves == wave)
+                for (int line = blockIdx.x; line < hot_lines(a); line += gridDim.x) hot_sweep_line(a, line);
+        }
         const bool works = active;
         if (active && !have) {
             const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
@@ -896,12 +969,13 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
     if constexpr (HOT) {          // publish whatever is still pending
         __syncthreads();
         for (int k = threadIdx.x; k < a.n_hot * F; k += blockDim.x) {
-            const float d = lds_tables[k];
-            if (d != 0.0f) atomic_add_f32(a.v_i + (size_t)a.hot_item[k / F] * F + (k % F), d);
+            const float d = (float)step.hot_acc[k] * Step::kHotUnit;
+            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.v_i + (size_t)a.hot_item[k / F] * F + (k % F)
+                                                       : a.hot_bins_v + (size_t)(blockIdx.x % kHotBins) * a.n_hot * F + k, d);
         }
         for (int k = threadIdx.x; k < a.n_hot; k += blockDim.x) {
-            const float d = lds_tables[a.n_hot * F + k];
-            if (d != 0.0f) atomic_add_f32(a.w_i + a.hot_item[k], d);
+            const float d = (float)step.hot_accw[k] * Step::kHotUnit;
+            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + a.hot_item[k] : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + k, d);
         }
     }
     if constexpr (FEAT) {

@@ -226,10 +226,13 @@ def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
     rep = sess.run(epochs=2)
     g = sess.weights_to_host()
     o, out = _oracle_in_engine_order(oracle, (pairs, csr, sw, x_uf, x_if, None), w, 1, 2, 1492)
-    # log-likelihood: 2.5 % in the first epoch (measured +1.96 %: the 64 hottest items are trained through per-workgroup LDS
-    # accumulators and damped accordingly, which costs them a little progress early on), 1.5 % in the second (measured +1.1 %)
-    _assert_statistical_parity(g, rep, o, out, ll_tol=0.025)
-    np.testing.assert_allclose(rep["log_likelihood"][1:], out["ll"][1:], rtol=0.015)
+    # log-likelihood: 1.8 % in the first epoch (measured +1.2 %: the 64 hottest items are trained through per-workgroup LDS
+    # accumulators and damped accordingly, which costs them a little progress early on), 1.2 % in the second (measured +0.8 %);
+    # norms measured +0.03 % / +0.12 % / +0.7 % (v_u, v_i, w_i)
+    print("full-size config 2: LL gpu/oracle - 1 =", rep["log_likelihood"] / out["ll"] - 1.0, " norms gpu/oracle - 1 =",
+          [float(np.linalg.norm(g[k]) / np.linalg.norm(o[k]) - 1.0) for k in ("v_u", "v_i", "w_i")])
+    _assert_statistical_parity(g, rep, o, out, ll_tol=0.018)
+    np.testing.assert_allclose(rep["log_likelihood"][1:], out["ll"][1:], rtol=0.012)
 
 
 @pytest.mark.parametrize("damping", [-1.0, 1e9])
