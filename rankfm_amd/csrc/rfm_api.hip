@@ -119,6 +119,16 @@ __global__ void degree_check_kernel(const int64_t *__restrict__ off, int n_users
 // ---------------------------------------------------------------------------------------------
 // Hogwild plan: per-item step scale from item popularity (see SgdArgs::pos_scale)
 // ---------------------------------------------------------------------------------------------
+constexpr int kBiasStride = 16;
+// item biases <-> their padded copy (SgdArgs::w_stride); PAD: w_pad[i * 16] = w_i[i], else the reverse
+template <bool PAD>
+__global__ void bias_pad_kernel(float *__restrict__ w_i, float *__restrict__ w_pad, int n_items) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    if (PAD) w_pad[(size_t)i * kBiasStride] = w_i[i];
+    else w_i[i] = w_pad[(size_t)i * kBiasStride];
+}
+
 __global__ void item_count_kernel(const int32_t *__restrict__ interactions, long long n, int *__restrict__ count) {
     for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x)
         atomicAdd(count + interactions[2 * r + 1], 1);
@@ -162,6 +172,7 @@ struct Workspace {
     unsigned int *error_flags;    // [1] (+pad)
     uint32_t *mt_state;           // [625] (+pad)
     float *multiplier;            // [max_samples + 1]
+    float *w_pad;                     // [n_items * kBiasStride] item biases, one 64-byte line each (SgdArgs::w_stride)
     float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: zero between launches
     float *feat_snapshot;         // [(P+Q)*F + Q] feature tables at launch start (LDS-replica merge)
     size_t bytes;
@@ -191,6 +202,7 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
     w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
     w.feat_snapshot = (float *)(p + o);          o += align_up(sizeof(float) * n_feat_tab);
+    w.w_pad = (float *)(p + o);                  o += align_up(sizeof(float) * (size_t)kBiasStride * (size_t)n_items);
     w.hot_bins_v = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot * (size_t)n_factors);
     w.hot_bins_w = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot);
     w.bytes = o;
@@ -487,6 +499,12 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         RFM_HIP(hipStreamSynchronize(stream));              // pageable host vectors
     }
 
+    // Hogwild launches work on the padded copy of the item biases; it is written back after every epoch (the tail kernel
+    // and the caller read w_i)
+    // (WARP reads a bias per candidate, ~20 per update: there the 16x larger table costs more in read misses than the
+    // atomics gain -- config 3: 318 M updates/s unpadded, 306 M padded -- so only BPR-like sampling pads)
+    const bool pad_bias = !serial && cfg->max_samples <= 4;
+    if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, cfg->n_items);
     std::vector<hipEvent_t> ev((size_t)2 * E, nullptr);
     const bool timing = rep && rep->sgd_kernel_ms;
     if (timing)
@@ -497,7 +515,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         SgdArgs a;
         a.interactions = b->interactions; a.sample_weight = b->sample_weight;
         a.csr_off = b->csr_offsets; a.csr_items = b->csr_items; a.x_uf = b->x_uf; a.x_if = b->x_if;
-        a.w_i = b->w_i; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
+        a.w_i = pad_bias ? ws.w_pad : b->w_i; a.w_stride = pad_bias ? kBiasStride : 1; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
         a.perm = b->perms ? b->perms + (size_t)e * N : nullptr;
         a.multiplier = ws.multiplier; a.mt_state = ws.mt_state;
         a.ll = ws.ll + e; a.draws = ws.draws + e; a.error_flags = ws.error_flags;
@@ -554,6 +572,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             }
             launch(a, grid, stream);
         }
+        if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, cfg->n_items);
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));
 
         if (cfg->check_finite || cfg->want_penalty) {

@@ -42,6 +42,11 @@ struct SgdArgs {
     const float *__restrict__ x_uf;             // [U,P]
     const float *__restrict__ x_if;             // [I,Q]
     float *w_i, *w_if, *v_u, *v_i, *v_uf, *v_if;
+    // Hogwild kernels address the item biases as w_i[i * w_stride]: with w_stride = 16 every bias has a 64-byte line of
+    // its own (a padded copy in the workspace).  Sixteen biases per line means the two bias atomics of every in-flight
+    // update collide on ~3000 lines and retire serially memory-side: they cost as much as the four atomics of an item
+    // row (measured on config 2, uniform items: 2.88 ms with, 2.37 ms without the bias atomics).
+    int32_t w_stride;
     const int32_t *__restrict__ perm;           // this epoch's visiting order [N] or nullptr        (rows kernel)
     const float *__restrict__ sw_csr;           // [N] sample weight by CSR position                 (segments kernel)
     const int4 *__restrict__ seg_desc;          // [S] {user, first CSR position, length, 0}         (segments kernel)
@@ -390,7 +395,7 @@ struct RowStep {
     __device__ __forceinline__ float utility(const float (&vu)[KPL], const float (&A)[KPL], int32_t it, float (&vi)[KPL],
                                              float (&B)[KPL], float &wi, int slot = -1, const XV *xit = nullptr) const {
         load_row<FRESH>(a.v_i + (size_t)it * F, vi);
-        wi = load_f32<FRESH>(a.w_i + it);
+        wi = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
         if constexpr (HOT) {
             if (slot >= 0) {      // the workgroup's own pending updates of a hot row are part of its view of the row
 #pragma unroll
@@ -509,7 +514,7 @@ struct RowStep {
                     wc[q] = 0.0f;
                     if (!mem[q]) {
                         load_row<FRESH>(a.v_i + (size_t)c[q] * F, vc[q]);
-                        wc[q] = load_f32<FRESH>(a.w_i + c[q]);
+                        wc[q] = load_f32<FRESH>(a.w_i + (size_t)c[q] * a.w_stride);
                     }
                 }
 #pragma unroll
@@ -557,8 +562,8 @@ struct RowStep {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
             if (HOT && slot >= 0) hot_add(hot_accw + slot, dwi);
-            else if (!skip_pos) apply_f32<SERIAL>(a.w_i + i, wi, dwi, plain_items);
-            apply_f32<SERIAL>(a.w_i + j, wj, dwj, plain_items);
+            else if (!skip_pos) apply_f32<SERIAL>(a.w_i + (size_t)i * a.w_stride, wi, dwi, plain_items);
+            apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj, plain_items);
         }
 
         // item-feature weights (:283-286): every q shrinks, lanes split the q range
@@ -612,7 +617,7 @@ struct RowStep {
                     }
                     if (sub == 0) {
                         const float d = hot_take(hot_accw + slot);
-                        if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + i : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + slot, d);
+                        if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)i * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + slot, d);
                     }
                 }
             }
@@ -821,7 +826,7 @@ __device__ __forceinline__ void hot_sweep_line(const SgdArgs &a, int line) {
         ok = slot < a.n_hot;
         src = a.hot_bins_w + slot;
         bin_stride = (size_t)a.n_hot;
-        dst = a.w_i + a.hot_item[ok ? slot : 0];
+        dst = a.w_i + (size_t)a.hot_item[ok ? slot : 0] * a.w_stride;
     }
     float acc = 0.0f;
     if (ok) {
@@ -975,7 +980,7 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         }
         for (int k = threadIdx.x; k < a.n_hot; k += blockDim.x) {
             const float d = (float)step.hot_accw[k] * Step::kHotUnit;
-            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + a.hot_item[k] : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + k, d);
+            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + k, d);
         }
     }
     if constexpr (FEAT) {
