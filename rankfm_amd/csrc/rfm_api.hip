@@ -503,7 +503,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // and the caller read w_i)
     // (WARP reads a bias per candidate, ~20 per update: there the 16x larger table costs more in read misses than the
     // atomics gain -- config 3: 318 M updates/s unpadded, 306 M padded -- so only BPR-like sampling pads)
-    const bool pad_bias = !serial && cfg->max_samples <= 4;
+    const bool pad_bias = !serial && cfg->max_samples <= 4 && !getenv("RFM_NO_BIAS_PAD");   // (experiment knob)
     if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, cfg->n_items);
     std::vector<hipEvent_t> ev((size_t)2 * E, nullptr);
     const bool timing = rep && rep->sgd_kernel_ms;
