@@ -530,7 +530,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.max_groups = max_groups;
         a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
         a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w;
-        a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 2 * grid ? 1 : 0;   // see SgdArgs::hot_bins_v
+        a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * grid ? 1 : 0;   // see SgdArgs::hot_bins_v
         a.feat_snapshot = ws.feat_snapshot;
         a.feat_merge = 1.0f / (float)grid;
         a.block_threads = waves_per_block * 64;

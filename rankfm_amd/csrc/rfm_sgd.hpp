@@ -103,8 +103,8 @@ struct SgdArgs {
     // addresses instead).  A workgroup adds its pending sums into bin (workgroup % kHotBins) of these arrays; every
     // 64-byte line of the bins has an owner workgroup that sweeps it every few rows (exchange with zero over the bins,
     // one atomic add of the total into v_i / w_i), and hot_reduce_kernel drains what is left when the launch ends.
-    // With few workgroups (fewer than half the lines) there is little contention and a line would wait long for its
-    // sweep: hot_direct = 1 publishes straight into the rows.
+    // With few workgroups (fewer than a quarter of the lines) there is little contention and a sweeping turn would take
+    // long: hot_direct = 1 publishes straight into the rows.
     float *hot_bins_v;                          // [kHotBins, n_hot, F]
     float *hot_bins_w;                          // [kHotBins, n_hot]
     int32_t hot_direct;
@@ -921,7 +921,7 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         if constexpr (!FEAT) { if (!__any(active)) break; }
         if constexpr (HOT) {
             // bin sweeping duty (see SgdArgs::hot_bins_v): the wavefronts of a workgroup take turns, one turn per row; a turn
-            // sweeps the workgroup's lines (at most two, else the host chose hot_direct)
+            // sweeps the workgroup's lines (at most four, else the host chose hot_direct)
             const int n_waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
             if (!a.hot_direct && iter % n_waves == wave)
                 for (int line = blockIdx.x; line < hot_lines(a); line += gridDim.x) hot_sweep_line(a, line);
