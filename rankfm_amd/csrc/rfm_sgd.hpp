@@ -469,17 +469,60 @@ struct RowStep {
             }
         }
         float vi[KPL], Bi[KPL], wi;
-        const float ut_ui = utility(vu, A, i, vi, Bi, wi, slot, &xi);    // :239
-
-        // WARP sampling loop (:244-264); BPR is max_samples == 1
         float vj[KPL], Bj[KPL], wj = 0.0f;
         float min_pu = 1e6f;
         int32_t j = -1;
         int sampled = 0;
-        constexpr bool BATCH_WARP = !SERIAL && !FEAT && WARPB;
-        // first draw (all of BPR): one candidate at a time
+        float ut_ui = 0.0f;
         int s = 1;
         bool done = false;
+        constexpr bool BATCH_WARP = !SERIAL && !FEAT && WARPB;
+        // BPR instantiation of the feature kernel: the one negative does not depend on any score, and both the pairwise
+        // utility and the gradients need the item-feature terms only as DIFFERENCES, so x_if[i] - x_if[j] is projected
+        // once instead of x_if[i] and x_if[j] separately:
+        //   pu = (w_i - w_j) + (x_i - x_j).w_if + <v_u + A, v_i - v_j> + <(x_i - x_j).v_if, v_u>
+        // (the reference's ut_ui - ut_uj, :239 and :256-257, regrouped; Bi then holds B(i) - B(j) and Bj zero)
+        constexpr bool BPRF = FEAT && LDSF && !WARPB;
+        if constexpr (BPRF) {
+            j = next_negative(lo, hi, row_key, attempt);
+            sampled = 1;
+            load_row<FRESH>(a.v_i + (size_t)i * F, vi);
+            load_row<FRESH>(a.v_i + (size_t)j * F, vj);
+            wi = load_f32<FRESH>(a.w_i + (size_t)i * a.w_stride);
+            wj = load_f32<FRESH>(a.w_i + (size_t)j * a.w_stride);
+            float scalar = 0.0f;
+            zero(Bi);
+            zero(Bj);
+            if (a.has_if) {
+                xload(a.x_if + (size_t)j * a.n_if, a.n_if, xj);
+                float sc = 0.0f;
+                if (a.n_if <= G * MAXR) {
+                    XV dxv = xi;
+#pragma unroll
+                    for (int k = 0; k < MAXR; ++k) dxv.r[k] = xi.r[k] - xj.r[k];
+                    project(dxv, t_v_if, Bi);
+#pragma unroll
+                    for (int k = 0; k < MAXR; ++k)
+                        if (sub + G * k < a.n_if) sc += dxv.r[k] * t_w_if[sub + G * k];
+                } else {
+                    float Bn[KPL];
+                    project(xi, t_v_if, Bi);
+                    project(xj, t_v_if, Bn);
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k) Bi[k] -= Bn[k];
+                    xown2(xi, xj, [&](int q, float xa, float xb) { sc += (xa - xb) * t_w_if[q]; });
+                }
+                scalar = group_sum<G>(sc);
+            }
+            float part = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) part += (vu[k] + A[k]) * (vi[k] - vj[k]) + Bi[k] * vu[k];
+            min_pu = (wi - wj) + scalar + group_sum<G>(part);
+        } else {
+        ut_ui = utility(vu, A, i, vi, Bi, wi, slot, &xi);    // :239
+
+        // WARP sampling loop (:244-264); BPR is max_samples == 1
+        // first draw (all of BPR): one candidate at a time
         for (; s <= ((BATCH_WARP || (!SERIAL && !FEAT && !WARPB)) ? 1 : a.max_samples); ++s) {
             const int32_t cand = next_negative(lo, hi, row_key, attempt);
             float vc[KPL], Bc[KPL], wc;
@@ -494,6 +537,7 @@ struct RowStep {
                 for (int k = 0; k < KPL; ++k) { vj[k] = vc[k]; if constexpr (FEAT) Bj[k] = Bc[k]; }
             }
             if (pu < kMargin) { done = true; break; }                     // :263-264
+        }
         }
         if constexpr (BATCH_WARP) {
             // Later draws four at a time: the draw stream is keyed by (row, attempt), so looking ahead is free.  Four raw
