@@ -551,36 +551,43 @@ struct RowStep {
                 for (int q = 0; q < 4; ++q) c[q] = (int32_t)rfm_draw_to_item(rfm_draw(row_key, attempt + q), (uint32_t)a.n_items);
                 attempt += 4;
                 members4_group<G>(a.csr_items, lo, hi, c, mem, sub);
-                float vc[4][KPL], wc[4], part[4];
+                // rows are fetched NB at a time: four at KPL <= 6; two at KPL >= 8, where four rows of registers spill and two
+                // rows are as many requests in flight as four rows at KPL = 4
+                constexpr int NB = KPL >= 8 ? 2 : 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    part[q] = 0.0f;
-                    wc[q] = 0.0f;
-                    if (!mem[q]) {
-                        load_row<FRESH>(a.v_i + (size_t)c[q] * F, vc[q]);
-                        wc[q] = load_f32<FRESH>(a.w_i + (size_t)c[q] * a.w_stride);
+                for (int q0 = 0; q0 < 4; q0 += NB) {
+                    if (done) break;
+                    float vc[NB][KPL], wc[NB], part[NB];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        part[q] = 0.0f;
+                        wc[q] = 0.0f;
+                        if (!mem[q0 + q]) {
+                            load_row<FRESH>(a.v_i + (size_t)c[q0 + q] * F, vc[q]);
+                            wc[q] = load_f32<FRESH>(a.w_i + (size_t)c[q0 + q] * a.w_stride);
+                        }
                     }
-                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (!mem[q]) {
+                    for (int q = 0; q < NB; ++q)
+                        if (!mem[q0 + q]) {
 #pragma unroll
-                        for (int k = 0; k < KPL; ++k) part[q] += vu[k] * vc[q][k];
+                            for (int k = 0; k < KPL; ++k) part[q] += vu[k] * vc[q][k];
+                        }
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) part[q] = group_sum<G>(part[q]);
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        if (done || mem[q0 + q] || s > a.max_samples) continue;
+                        const float pu = ut_ui - (wc[q] + part[q]);
+                        sampled = s;
+                        ++s;
+                        if (pu < min_pu) {
+                            min_pu = pu; j = c[q0 + q]; wj = wc[q];
+#pragma unroll
+                            for (int k = 0; k < KPL; ++k) vj[k] = vc[q][k];
+                        }
+                        if (pu < kMargin) done = true;
                     }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) part[q] = group_sum<G>(part[q]);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (done || mem[q] || s > a.max_samples) continue;
-                    const float pu = ut_ui - (wc[q] + part[q]);
-                    sampled = s;
-                    ++s;
-                    if (pu < min_pu) {
-                        min_pu = pu; j = c[q]; wj = wc[q];
-#pragma unroll
-                        for (int k = 0; k < KPL; ++k) vj[k] = vc[q][k];
-                    }
-                    if (pu < kMargin) done = true;
                 }
                 if (attempt >= kMaxAttempts) { if (sub == 0) atomicOr(a.error_flags, 1u); break; }
             }
