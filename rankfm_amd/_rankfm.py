@@ -112,10 +112,16 @@ class UserItemsCSR(Mapping):
         """sorted-unique... NOT unique: the reference keeps duplicates (rankfm/rankfm.py:174 sorts, does not dedupe)"""
         user_idx = np.asarray(user_idx, dtype=np.int64)
         item_idx = np.asarray(item_idx, dtype=np.int64)
-        order = np.lexsort((item_idx, user_idx))
         counts = np.bincount(user_idx, minlength=n_users)
         off = np.zeros(n_users + 1, dtype=np.int64)
         np.cumsum(counts, out=off[1:])
+        bound = int(item_idx.max()) + 1 if len(item_idx) else 1
+        if n_users * bound < 2 ** 62:
+            # one int64 key per pair and a plain sort: ~10x faster than lexsort at 5 M pairs (numpy sorts int64 with SIMD)
+            key = user_idx * bound + item_idx
+            key.sort()
+            return cls(off, (key % bound).astype(np.int32))
+        order = np.lexsort((item_idx, user_idx))
         return cls(off, item_idx[order].astype(np.int32))
 
     @classmethod
