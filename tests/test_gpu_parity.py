@@ -170,6 +170,22 @@ def test_hogwild_features_statistical_parity(oracle):
         assert 0.33 < np.linalg.norm(g[k]) / np.linalg.norm(o[k]) < 3.0, k
 
 
+def test_hogwild_wide_feature_tables_use_smaller_workgroups(oracle):
+    """k=128 with 40 + 40 tags: replica + two staging areas of a 1024-thread workgroup exceed the 160 KB of LDS, so the host
+    halves the workgroup (rfm_api.hip, feat_waves) -- the 512-thread geometry of the feature kernel, its MFMA tiling with 8
+    wavefronts and the > 64 KB dynamic-LDS launch are only reached here.  At the smaller step dense tags need.  Measured:
+    factor norms within 1 %, log-likelihood +5 % / -0.1 % (epochs 1 / 2); the item biases end 20 % larger than the oracle's
+    (15 % with the 1024-thread geometry at F=64 on the same tags): 40 random item tags put the replicas' w_if noise
+    (+-30 % run to run) straight into the bias gradients, so w_i is only checked for scale."""
+    prob = _problem(U=3000, I=2000, N=120_000, F=128, seed=33, n_uf=40, n_if=40)
+    g, rep, o, out = _both(oracle, prob, max_samples=1, epochs=2, lr=0.02)
+    _assert_statistical_parity(g, rep, o, out, names=("v_u", "v_i"), norm_tol=0.05, ll_tol=0.08, corr=0.85)
+    assert 0.7 < np.linalg.norm(g["w_i"]) / np.linalg.norm(o["w_i"]) < 1.4
+    for k in ("v_uf", "v_if", "w_if"):
+        assert np.isfinite(g[k]).all()
+        assert 0.33 < np.linalg.norm(g[k]) / np.linalg.norm(o[k]) < 3.0, k
+
+
 def test_ranking_quality_matches_oracle_on_planted_data(oracle):
     """The quality bar of BASELINE.json: hit_rate@10 of the Hogwild engine within 1 point (abs) of the sequential oracle, factor
     norms within 2 %, on a planted-structure problem (MovieLens-1M-shaped generator at 1/3 scale), same initial weights,
