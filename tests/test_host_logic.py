@@ -189,3 +189,23 @@ def test_save_load_round_trip(tmp_path):
     assert r.user_to_index.loc["u30"] == m.user_to_index.loc["u30"]
     assert np.array_equal(r.user_items.items, m.user_items.items) and np.array_equal(r.x_uf, m.x_uf)
     assert r._lookup(np.array(["u20", "nobody"], dtype=object), "user").tolist() == [m.user_to_index.loc["u20"], -1]
+
+
+def test_user_items_csr_from_pairs_keeps_duplicates_and_sorts_within_user(monkeypatch):
+    """rankfm/rankfm.py:174 sorts each user's observed items and keeps duplicates; the key-sort fast path and the lexsort
+    fallback must both produce exactly that"""
+    from rankfm_amd import _rankfm
+    from rankfm_amd._rankfm import UserItemsCSR
+    rng = np.random.default_rng(3)
+    u = rng.integers(0, 50, 4000)
+    i = rng.integers(0, 30, 4000)                       # many duplicate pairs
+    want_off = np.concatenate([[0], np.cumsum(np.bincount(u, minlength=52))])
+    want_items = i[np.lexsort((i, u))].astype(np.int32)
+    fast = UserItemsCSR.from_pairs(u, i, 52)            # users 50, 51 have no rows
+    assert np.array_equal(fast.offsets, want_off) and np.array_equal(fast.items, want_items)
+    assert len(fast[51]) == 0 and np.array_equal(fast[7], np.sort(i[u == 7]))
+    monkeypatch.setattr(_rankfm, "_KEY_LIMIT", 1)       # index space too large for one int64 key: lexsort path
+    slow = UserItemsCSR.from_pairs(u, i, 52)
+    assert np.array_equal(slow.items, want_items) and np.array_equal(slow.offsets, want_off)
+    empty = UserItemsCSR.from_pairs(np.zeros(0, np.int64), np.zeros(0, np.int64), 4)
+    assert empty.offsets.tolist() == [0, 0, 0, 0, 0] and len(empty.items) == 0
