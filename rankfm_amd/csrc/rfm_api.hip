@@ -138,7 +138,8 @@ __global__ void item_count_kernel(const int32_t *__restrict__ interactions, long
 // hold item i (duplicates of a pair occupy consecutive positions).  `sw_csr` is pre-filled with the sentinel 0xFFFFFFFF.
 __global__ void sw_to_csr_kernel(const int32_t *__restrict__ interactions, const float *__restrict__ sw, long long n,
                                  const int64_t *__restrict__ off, const int32_t *__restrict__ items, unsigned int *sw_csr,
-                                 unsigned int *error_flags) {
+                                 unsigned int *error_flags, unsigned int *sw_max_bits) {
+    float sw_max = 0.0f;          // largest |sample weight|: scales the fixed-point hot-row accumulators (SgdArgs::sw_max_bits)
     for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
         const int32_t u = interactions[2 * r], i = interactions[2 * r + 1];
         int64_t lo = off[u];
@@ -152,7 +153,10 @@ __global__ void sw_to_csr_kernel(const int32_t *__restrict__ interactions, const
         for (int64_t slot = lo; slot < end && items[slot] == i; ++slot)
             if (atomicCAS(sw_csr + slot, 0xFFFFFFFFu, __float_as_uint(sw[r])) == 0xFFFFFFFFu) { placed = true; break; }
         if (!placed) atomicOr(error_flags, 4u);             // the CSR lists do not describe these interactions
+        sw_max = fmaxf(sw_max, fabsf(sw[r]));
     }
+    for (int m = 32; m > 0; m >>= 1) sw_max = fmaxf(sw_max, __shfl_xor(sw_max, m));
+    if ((threadIdx.x & 63) == 0 && sw_max > 0.0f) atomicMax(sw_max_bits, __float_as_uint(sw_max));   // non-negative floats order like their bits
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -164,6 +168,7 @@ struct Workspace {
     int4 *seg_desc;               // [<= U + N / kSegmentRows]  persistent
     int32_t *hot_item;            // [kMaxHot] persistent
     int32_t *hot_period;          // [kMaxHot] persistent
+    unsigned int *sw_max_bits;    // bits of max |sample_weight| (persistent, written with the plan)
     size_t volatile_offset;       // everything from here on is zeroed at the start of every call
     double *ll;                   // [epochs]
     unsigned long long *draws;    // [epochs]
@@ -193,6 +198,7 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.seg_desc = (int4 *)(p + o);                o += align_up(sizeof(int4) * max_segments(n_rows, n_users));
     w.hot_item = (int32_t *)(p + o);             o += align_up(sizeof(int32_t) * kMaxHot);
     w.hot_period = (int32_t *)(p + o);           o += align_up(sizeof(int32_t) * kMaxHot);
+    w.sw_max_bits = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int));
     w.volatile_offset = o;
     w.ll = (double *)(p + o);                    o += align_up(sizeof(double) * epochs);
     w.draws = (unsigned long long *)(p + o);     o += align_up(sizeof(unsigned long long) * epochs);
@@ -366,8 +372,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         n_segments = (int64_t)desc.size();
         RFM_HIP(hipMemcpyAsync(ws.seg_desc, desc.data(), sizeof(int4) * desc.size(), hipMemcpyHostToDevice, stream));
         RFM_HIP(hipMemsetAsync(ws.sw_csr, 0xFF, sizeof(float) * (size_t)N, stream));
+        RFM_HIP(hipMemsetAsync(ws.sw_max_bits, 0, sizeof(unsigned int), stream));
         sw_to_csr_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, b->sample_weight, (long long)N, b->csr_offsets,
-                                                                 b->csr_items, (unsigned int *)ws.sw_csr, ws.error_flags);
+                                                                 b->csr_items, (unsigned int *)ws.sw_csr, ws.error_flags, ws.sw_max_bits);
         unsigned int flags = 0;
         RFM_HIP(hipMemcpyAsync(&flags, ws.error_flags, sizeof flags, hipMemcpyDeviceToHost, stream));
         RFM_HIP(hipStreamSynchronize(stream));                        // also: `desc` is pageable host memory
@@ -529,7 +536,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.single_group = single_group ? 1 : 0;
         a.max_groups = max_groups;
         a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
-        a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w;
+        a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w; a.sw_max_bits = ws.sw_max_bits;
         a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * grid ? 1 : 0;   // see SgdArgs::hot_bins_v
         a.feat_snapshot = ws.feat_snapshot;
         a.feat_merge = 1.0f / (float)grid;

@@ -108,6 +108,7 @@ struct SgdArgs {
     float *hot_bins_v;                          // [kHotBins, n_hot, F]
     float *hot_bins_w;                          // [kHotBins, n_hot]
     int32_t hot_direct;
+    const unsigned int *sw_max_bits;            // bits of max |sample_weight| (plan): range of the fixed-point hot sums
 };
 constexpr int kHotBins = 16;
 
@@ -278,17 +279,18 @@ struct RowStep {
     lds_float *st_row = nullptr, *st_nvu = nullptr, *st_dij = nullptr, *st_xu = nullptr, *st_dx = nullptr;
     int wg_group = 0;
     // LDS [n_hot, F] pending factor deltas, [n_hot] pending bias deltas, [n_hot] touch counters.  The pending sums are
-    // 32-bit FIXED POINT (units of 2^-24, +-128): ds_add_u32 takes ~5 clocks per wave instruction where ds_add_f32 takes
-    // ~3 clocks per active lane (tools/microbench/lds_atomic.hip), and every cross-lane shuffle of the workgroup queues
-    // behind them in the same LDS pipeline.  A pending sum stays far inside the range (<= 64 touches of steps < 0.3).
+    // 32-bit FIXED POINT: ds_add_u32 takes ~5 clocks per wave instruction where ds_add_f32 takes ~3 clocks per active
+    // lane (tools/microbench/lds_atomic.hip), and every cross-lane shuffle of the workgroup queues behind them in the
+    // same LDS pipeline.  The unit is 2^-24 * max(1, 10 * eta * max |sample_weight|), the range +-128 times that: a
+    // pending sum is at most 64 touches of steps eta * sample_weight * |v|, i.e. < 0.3 at eta = 0.1 and unit weights.
     lds_int *hot_acc = nullptr;
     lds_int *hot_accw = nullptr;
     lds_int *hot_cnt = nullptr;
-    static constexpr float kHotScale = 16777216.0f, kHotUnit = 1.0f / 16777216.0f;
-    static __device__ __forceinline__ void hot_add(lds_int *p, float v) {
+    float kHotScale = 16777216.0f, kHotUnit = 1.0f / 16777216.0f;
+    __device__ __forceinline__ void hot_add(lds_int *p, float v) const {
         __hip_atomic_fetch_add(p, __float2int_rn(v * kHotScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    static __device__ __forceinline__ float hot_take(lds_int *p) {
+    __device__ __forceinline__ float hot_take(lds_int *p) const {
         return (float)__hip_atomic_exchange(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * kHotUnit;
     }
 
@@ -953,6 +955,10 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         step.hot_acc = (lds_int *)lds;
         step.hot_accw = (lds_int *)(lds + a.n_hot * F);
         step.hot_cnt = (lds_int *)(lds + a.n_hot * (F + 1));
+        // steps scale with learning rate x sample weight: unit 2^-24 at the defaults (eta 0.1, weights <= 1)
+        const float range = fmaxf(1.0f, __uint_as_float(*a.sw_max_bits) * a.eta * 10.0f);
+        step.kHotScale = 16777216.0f / range;
+        step.kHotUnit = range / 16777216.0f;
     }
 
     double ll_acc = 0.0;
@@ -1025,12 +1031,12 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
     if constexpr (HOT) {          // publish whatever is still pending
         __syncthreads();
         for (int k = threadIdx.x; k < a.n_hot * F; k += blockDim.x) {
-            const float d = (float)step.hot_acc[k] * Step::kHotUnit;
+            const float d = (float)step.hot_acc[k] * step.kHotUnit;
             if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.v_i + (size_t)a.hot_item[k / F] * F + (k % F)
                                                        : a.hot_bins_v + (size_t)(blockIdx.x % kHotBins) * a.n_hot * F + k, d);
         }
         for (int k = threadIdx.x; k < a.n_hot; k += blockDim.x) {
-            const float d = (float)step.hot_accw[k] * Step::kHotUnit;
+            const float d = (float)step.hot_accw[k] * step.kHotUnit;
             if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + k, d);
         }
     }

@@ -146,6 +146,15 @@ def test_hogwild_bpr_statistical_parity(oracle, F):
     _assert_statistical_parity(*_both(oracle, prob, max_samples=1, epochs=3))
 
 
+def test_hogwild_large_sample_weights_scale_the_hot_row_accumulators(oracle):
+    """Sample weights of 200..800 with the learning rate divided by 500: the same trajectory scale as unit weights at 0.1, but
+    the hot rows' fixed-point LDS sums must take their unit from learning rate x largest weight (RowStep::kHotScale) --
+    with the unit of the defaults the pending sums would be fine here, with a unit from the weights alone 5 % rounding noise."""
+    prob = list(_problem(U=4000, I=2500, N=200_000, F=64, seed=74))
+    prob[2] = np.random.default_rng(5).uniform(200.0, 800.0, len(prob[0])).astype(np.float32)
+    _assert_statistical_parity(*_both(oracle, tuple(prob), max_samples=1, epochs=3, lr=0.1 / 500.0))
+
+
 def test_hogwild_warp_statistical_parity(oracle):
     prob = _problem(U=4000, I=2500, N=200_000, F=64, seed=3, sigma=0.3)
     g, rep, o, out = _both(oracle, prob, max_samples=20, epochs=3)
