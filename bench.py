@@ -42,14 +42,12 @@ def algorithmic_bytes_per_update(F, n_uf=0, n_if=0, draws=1.0):
     return b
 
 
-def cpu_baseline(pairs, csr, F, seconds_budget=25.0):
-    """time the CPU restatement (oracle = checker infrastructure, used here only as the reported baseline)"""
+def cpu_baseline(shard, x_if, w, hyper, has_uf, has_if, seconds_budget=25.0):
+    """time the CPU restatement (oracle = checker infrastructure, used here only as the reported baseline) on the same
+    workload: same interactions, features, loss and max_samples, from the same initial weights"""
     from oracle import oracle as orc
-    from rankfm_amd import synthetic
-    U, I, N = len(csr.offsets) - 1, int(pairs[:, 1].max()) + 1, len(pairs)
-    I = max(I, 2)
-    w = synthetic.init_weights(U, I, F, seed=1492)
-    x_uf, x_if = np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32)
+    pairs, off, items, x_uf = shard["interactions"], shard["csr_offsets"], shard["csr_items"], shard["x_uf"]
+    N = len(pairs)
     sw = np.ones(N, dtype=np.float32)
     rng = np.random.default_rng(0)
 
@@ -57,22 +55,23 @@ def cpu_baseline(pairs, csr, F, seconds_budget=25.0):
         perm = rng.permutation(N)[:n_rows].astype(np.int32)
         sub = np.ascontiguousarray(pairs[perm])                   # a random sample of the same workload's rows
         p = np.arange(n_rows, dtype=np.int32)[None, :]
-        ww = {k: v.copy() for k, v in w.items()}
+        ww = {k: np.array(v, dtype=np.float32, copy=True) for k, v in w.items()}
         t0 = time.perf_counter()
-        orc.fit(sub, sw[:n_rows], csr.offsets, csr.items, x_uf, x_if, ww["w_i"], ww["w_if"], ww["v_u"], ww["v_i"],
-                ww["v_uf"], ww["v_if"], 0.01, 0.1, 0.1, "constant", 0.25, 1, 1, perms=p,
-                rng_mode=orc.RNG_MT19937, seed=1492, membership="linear")
+        orc.fit(sub, sw[:n_rows], off, items, x_uf, x_if, ww["w_i"], ww["w_if"], ww["v_u"], ww["v_i"],
+                ww["v_uf"], ww["v_if"], 0.01, 0.1, hyper["learning_rate"], "constant", 0.25, hyper["max_samples"], 1, perms=p,
+                rng_mode=orc.RNG_MT19937, seed=1492, membership="linear", has_uf=has_uf, has_if=has_if)
         return time.perf_counter() - t0
 
-    probe = min(N, 500_000)
+    probe = min(N, 300_000)
     t = run(probe)
     rate = probe / t
     n_rows = int(min(N, max(probe, rate * seconds_budget * 0.6)))
     t = run(n_rows)
     return dict(value=n_rows / t, unit="updates/s", cores=1, kind="port",
-                sample="%d randomly sampled rows of the same workload, 1 epoch, oracle/rfm_oracle.c (gcc -O2 -ffast-math, "
-                       "MT19937 + linear membership scan like the reference; 1.19x the time of the reference's Cython _fit per tools/calibrate_cpu.py), "
-                       "%.1f s on 1 core of %d" % (n_rows, t, os.cpu_count() or 0))
+                sample="%d randomly sampled rows of the same workload (same features / loss / max_samples, initial weights), 1 epoch, "
+                       "oracle/rfm_oracle.c (gcc -O2 -ffast-math, MT19937 + linear membership scan like the reference; 1.19x the time of "
+                       "the reference's Cython _fit at k=64 BPR per tools/calibrate_cpu.py), %.1f s on 1 core of %d"
+                       % (n_rows, t, os.cpu_count() or 0))
 
 
 def main():
@@ -92,6 +91,9 @@ def main():
     ap.add_argument("--syncs-per-epoch", type=int, default=1, help="item-delta exchanges per epoch (N > 1)")
     ap.add_argument("--factors", type=int, default=0, help="override the config's factor count (experiments)")
     ap.add_argument("--shape", type=int, default=0, help="experiment: 1-based index into the kernel shape table")
+    ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
+    ap.add_argument("--weak", action="store_true", help="configs 4 / 5: weak scaling (every rank its own config-sized shard)")
+    ap.add_argument("--learning-rate", type=float, default=0.0, help="override the config's learning rate")
     args = ap.parse_args()
 
     import torch
@@ -122,17 +124,39 @@ def main():
 
     cfg = synthetic.CONFIGS[args.config]
     U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
-    if args.factors > 0:
-        F = args.factors
     n_uf, n_if = cfg.get("n_user_features", 0), cfg.get("n_item_features", 0)
-    # each rank generates ITS OWN user shard (different seed) over the shared item catalogue
-    pairs, csr = synthetic.make_interactions(U, I, N, seed=1000 * rank, zipf_s=args.zipf)
-    w = synthetic.init_weights(U, I, F, n_uf, n_if, seed=1492 + rank)
-    x_uf = synthetic.make_features(U, n_uf, 7 + rank) if n_uf else np.zeros((U, 1), np.float32)
-    x_if = synthetic.make_features(I, n_if, 8) if n_if else np.zeros((I, 1), np.float32)
-    shard = dict(interactions=pairs, sample_weight=np.ones(N, np.float32), csr_offsets=csr.offsets, csr_items=csr.items,
-                 x_uf=x_uf, v_u=w["v_u"])
-    hyper = dict(alpha=0.01, beta=0.1, learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25,
+    lr = args.learning_rate if args.learning_rate > 0 else cfg.get("learning_rate", 0.1)
+    # Configs 4 and 5 are ONE data set sharded by user (STRONG scaling, as BASELINE.json words them): rank r of W trains the
+    # user shard r of W of the config's data (synthetic.make_config_shard; the interaction-balanced split of
+    # distributed.shard_boundaries falls on its block boundaries).  On one GPU, `--share S` runs the shard 0 of S -- what one
+    # of S GPUs holds (default 8, the configs' GPU count); `--share 1` the whole data set.  Configs 2 / 3 are single-GPU
+    # configs: with N > 1 every rank gets its own config-sized shard over the shared catalogue (WEAK scaling), which is also
+    # what `--weak` forces for 4 / 5.
+    strong = args.config in ("C4", "C5") and not args.weak
+    if strong:
+        parts = world if world > 1 else max(args.share, 1)
+        sh = synthetic.make_config_shard(args.config, rank=rank if world > 1 else 0, world=parts, zipf_s=args.zipf)
+        if args.factors > 0:
+            raise SystemExit("--factors needs --weak for configs 4 / 5")
+        pairs, w, x_if = sh["interactions"], sh["weights"], sh["x_if"]
+        shard = dict(interactions=pairs, sample_weight=sh["sample_weight"], csr_offsets=sh["csr_offsets"], csr_items=sh["csr_items"],
+                     x_uf=sh["x_uf"], v_u=w["v_u"])
+        from rankfm_amd._rankfm import UserItemsCSR
+        csr = UserItemsCSR(sh["csr_offsets"], sh["csr_items"])
+        n_local, u_local = len(pairs), sh["user_hi"] - sh["user_lo"]
+        n_job = n_local * world                     # every shard holds exactly N / parts interactions
+    else:
+        if args.factors > 0:
+            F = args.factors
+        # each rank generates ITS OWN user shard (different seed) over the shared item catalogue
+        pairs, csr = synthetic.make_interactions(U, I, N, seed=1000 * rank, zipf_s=args.zipf)
+        w = synthetic.init_weights(U, I, F, n_uf, n_if, seed=1492 + rank)
+        x_uf = synthetic.make_features(U, n_uf, 7 + rank) if n_uf else np.zeros((U, 1), np.float32)
+        x_if = synthetic.make_features(I, n_if, 8) if n_if else np.zeros((I, 1), np.float32)
+        shard = dict(interactions=pairs, sample_weight=np.ones(N, np.float32), csr_offsets=csr.offsets, csr_items=csr.items,
+                     x_uf=x_uf, v_u=w["v_u"])
+        n_local, u_local, n_job = N, U, N * world
+    hyper = dict(alpha=0.01, beta=0.1, learning_rate=lr, learning_schedule="constant", learning_exponent=0.25,
                  max_samples=cfg["max_samples"])
     trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
                                         syncs_per_epoch=args.syncs_per_epoch, seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
@@ -167,7 +191,8 @@ def main():
     assert np.isfinite(ll_last), "training diverged"
 
     if rank == 0:
-        total_updates = float(N) * world * args.steps
+        N = n_local
+        total_updates = float(n_job) * args.steps
         value = total_updates / elapsed
         launches = rep["launches_per_epoch"]
         mean_draws = draws / (float(N) * args.steps)
@@ -182,14 +207,22 @@ def main():
                 traffic = json.load(open(tpath)).get("%s_hbm_bytes_per_launch" % args.config)
             except Exception:
                 traffic = None
+        if strong:
+            what = ("%s: user shard %d of %d of ONE synthetic data set of %d users x %d items x %d interactions (this GPU: %d users, %d "
+                    "interactions, all items)" % (args.config, 0 if world == 1 else rank, world if world > 1 else max(args.share, 1), U, I, cfg["n_interactions"], u_local, n_local))
+        else:
+            what = "%s: synthetic %d users x %d items x %d interactions per GPU" % (args.config, U, I, N)
         out = {
             "metric": "(user,item,neg) pairwise updates/sec at k=64; achieved HBM GB/s vs peak",
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %d users x %d items x %d interactions per GPU, factors=%d, loss=%s, "
-                                   "zipf_s=%g, hogwild fp32 atomics, counter RNG" % (args.config, U, I, N, F, cfg["loss"], args.zipf),
-                       "n_users_total": U * world, "n_interactions_total": N * world, "parallelism": "user-shard dp%d" % world,
+            "config": {"workload": "%s, factors=%d, loss=%s%s%s, learning_rate=%g, zipf_s=%g, hogwild fp32 atomics, counter RNG"
+                                   % (what, F, cfg["loss"], " max_samples=%d" % cfg["max_samples"] if cfg["max_samples"] > 1 else "",
+                                      ", %d + %d dense user/item features" % (n_uf, n_if) if n_uf or n_if else "", lr, args.zipf),
+                       "n_users_total": u_local * world, "n_interactions_total": n_job, "parallelism": "user-shard dp%d" % world,
+                       "rccl_ranks_seen": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
+                       "collective_backend": dist.get_backend() if world > 1 else None,
                        "sgd_launches_per_epoch": launches, "waves_per_launch": rep["waves_per_launch"],
                        "mean_draws_per_update": mean_draws, "final_mean_ll_per_update": ll_last / N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -198,7 +231,7 @@ def main():
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pairs, csr, F)
+            out["cpu_baseline"] = cpu_baseline(shard, x_if, w, hyper, int(n_uf > 0), int(n_if > 0))
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RFM_ABI_VERSION 1
+#define RFM_ABI_VERSION 2
 
 typedef enum rfm_status {
     RFM_OK = 0,
@@ -83,7 +83,11 @@ typedef struct rfm_fit_config {
     float learning_exponent;
     int32_t max_samples;           /* 1 = BPR (rankfm/rankfm.py:294-295), >1 = WARP */
     int32_t epochs;                /* epochs to run in this call */
-    int32_t epoch_begin;           /* absolute index of the first one (learning-rate decay, counter keys) */
+    int32_t epoch_begin;           /* index of the first one for the learning-rate schedule (the reference restarts its
+                                      schedule at 0 on every call, rankfm/_rankfm.pyx:218-223) */
+    int32_t rng_epoch_offset;      /* added to the epoch index that keys the counter RNG and the device-generated order:
+                                      a resumed fit (fit_partial) passes the epochs already trained so that it does not
+                                      replay the first call's order and draws while its schedule restarts at 0 */
     int32_t mode;                  /* RFM_MODE_* */
     int32_t rng;                   /* RFM_RNG_* */
     uint32_t seed;                 /* MT seed (reference: 1492) or counter seed */

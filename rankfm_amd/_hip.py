@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankfm_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK = 0
 ERR_BAD_ARG, ERR_UNKNOWN_SCHEDULE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_USER_SATURATED, ERR_WORKSPACE = (
     -1, -2, -3, -4, -5, -6, -7)
@@ -28,7 +28,7 @@ class FitConfig(C.Structure):
         ("has_user_features", C.c_int32), ("has_item_features", C.c_int32),
         ("alpha", C.c_float), ("beta", C.c_float), ("learning_rate", C.c_float),
         ("learning_schedule", C.c_int32), ("learning_exponent", C.c_float),
-        ("max_samples", C.c_int32), ("epochs", C.c_int32), ("epoch_begin", C.c_int32),
+        ("max_samples", C.c_int32), ("epochs", C.c_int32), ("epoch_begin", C.c_int32), ("rng_epoch_offset", C.c_int32),
         ("mode", C.c_int32), ("rng", C.c_int32), ("seed", C.c_uint32),
         ("check_finite", C.c_int32), ("want_penalty", C.c_int32),
         ("n_workgroups", C.c_int32), ("rows_per_launch", C.c_int32),

@@ -169,10 +169,13 @@ def numpy_epoch_permutations(n_rows, epochs):
 
 def _fit(interactions, sample_weight, user_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
          alpha, beta, learning_rate, learning_schedule, learning_exponent, max_samples, epochs, verbose,
-         *, engine=None, epoch_begin=0, report=None):
+         *, engine=None, epoch_begin=0, rng_epoch_offset=0, report=None):
     """drop-in for rankfm._rankfm._fit (rankfm/_rankfm.pyx:122-142): trains IN PLACE, returns None.
 
     `report`, when a dict, receives per-epoch 'log_likelihood', 'reg_penalty', 'sgd_kernel_ms', 'n_draws'.
+    `rng_epoch_offset` (epochs trained by earlier calls) shifts the epoch index that keys the counter RNG and the keyed
+    visiting order, so that a resumed fit with a fixed engine seed does not replay the first call's order and draws; the
+    learning-rate schedule still restarts at `epoch_begin` (0) like the reference's (rankfm/_rankfm.pyx:218-223).
     """
     opt = (engine or DEFAULT_ENGINE).validated()
     _buffer(interactions, np.int32, 2, "interactions")
@@ -197,7 +200,7 @@ def _fit(interactions, sample_weight, user_items, x_uf, x_if, w_i, w_if, v_u, v_
         alpha=alpha, beta=beta, learning_rate=learning_rate,
         learning_schedule=_hip.SCHEDULE_CONSTANT if learning_schedule == "constant" else _hip.SCHEDULE_INVSCALING,
         learning_exponent=learning_exponent, max_samples=int(max_samples), epochs=epochs, epoch_begin=int(epoch_begin),
-        mode=_hip.MODE_SERIAL if opt.mode == "serial" else _hip.MODE_HOGWILD,
+        rng_epoch_offset=int(rng_epoch_offset), mode=_hip.MODE_SERIAL if opt.mode == "serial" else _hip.MODE_HOGWILD,
         rng=_hip.RNG_MT19937 if opt.rng == "mt19937" else _hip.RNG_COUNTER, seed=seed & 0xFFFFFFFF,
         check_finite=int(opt.check_finite), want_penalty=int(bool(verbose) or report is not None),
         n_workgroups=int(opt.n_workgroups), rows_per_launch=int(opt.rows_per_launch),

@@ -111,9 +111,18 @@ __global__ void __launch_bounds__(256) tail_kernel(const TailArgs t) {
 }
 
 // a user whose list holds every item would make the rejection sampler spin forever (rankfm/_rankfm.pyx:250-253)
-__global__ void degree_check_kernel(const int64_t *__restrict__ off, int n_users, int n_items, unsigned int *flag) {
+// The lists may hold duplicates (the reference keeps repeated (user, item) rows, rankfm/rankfm.py:174, and trains them
+// fine): what matters is the number of DISTINCT items, counted in the sorted list -- only for the rare list that is long
+// enough to matter.
+__global__ void degree_check_kernel(const int64_t *__restrict__ off, const int32_t *__restrict__ items, int n_users, int n_items,
+                                    unsigned int *flag) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < n_users && off[u + 1] - off[u] >= (int64_t)n_items) atomicOr(flag, 2u);
+    if (u >= n_users) return;
+    const int64_t lo = off[u], hi = off[u + 1];
+    if (hi - lo < (int64_t)n_items) return;
+    int64_t distinct = 1;
+    for (int64_t k = lo + 1; k < hi; ++k) distinct += (items[k] != items[k - 1]);
+    if (distinct >= (int64_t)n_items) atomicOr(flag, 2u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -225,7 +234,7 @@ static int validate(const rfm_fit_config *c) {
     if (c->n_interactions < 0 || c->n_interactions > 0x7fffffffLL) return RFM_ERR_BAD_ARG;   // int32 row ids, like the reference
     if (c->n_users < 1 || c->n_items < 2 || c->n_user_features < 1 || c->n_item_features < 1 || c->n_factors < 1)
         return RFM_ERR_BAD_ARG;
-    if (c->max_samples < 1 || c->epochs < 1 || c->epoch_begin < 0) return RFM_ERR_BAD_ARG;
+    if (c->max_samples < 1 || c->epochs < 1 || c->epoch_begin < 0 || c->rng_epoch_offset < 0) return RFM_ERR_BAD_ARG;
     if (c->epoch_parts > 1 && (c->epoch_part_index < 0 || c->epoch_part_index >= c->epoch_parts)) return RFM_ERR_BAD_ARG;
     if (c->learning_schedule != RFM_SCHEDULE_CONSTANT && c->learning_schedule != RFM_SCHEDULE_INVSCALING)
         return RFM_ERR_UNKNOWN_SCHEDULE;
@@ -339,7 +348,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     }
     // (skipped when the caller vouches for a cached plan: the lists were checked when it was built)
     if (cfg->plan_token <= 0)
-        degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, cfg->n_users,
+        degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, b->csr_items, cfg->n_users,
                                                                                           cfg->n_items, ws.error_flags);
 
     // ---- plan, part 1 (segments kernel): user segments.  A user of degree d is cut into ceil(d / 32) near-equal runs of
@@ -381,7 +390,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         if (flags & 4u) {                                             // same length, different content: not this call's rows
             use_segments = false;
             RFM_HIP(hipMemsetAsync(ws.error_flags, 0, sizeof(unsigned int) * 4, stream));
-            degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, cfg->n_users,
+            degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, b->csr_items, cfg->n_users,
                                                                                               cfg->n_items, ws.error_flags);
         }
     }
@@ -512,12 +521,34 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // atomics gain -- config 3: 318 M updates/s unpadded, 306 M padded -- so only BPR-like sampling pads)
     const bool pad_bias = !serial && cfg->max_samples <= 4 && !getenv("RFM_NO_BIAS_PAD");   // (experiment knob)
     if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, cfg->n_items);
-    std::vector<hipEvent_t> ev((size_t)2 * E, nullptr);
+    // timing events: destroyed on every exit path
+    struct Events {
+        std::vector<hipEvent_t> ev;
+        ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    } events;
+    std::vector<hipEvent_t> &ev = events.ev;
+    ev.assign((size_t)2 * E, nullptr);
     const bool timing = rep && rep->sgd_kernel_ms;
     if (timing)
         for (auto &e : ev) RFM_HIP(hipEventCreate(&e));
+    // The reference stops at the first epoch that ends non-finite (assert_finite, rankfm/_rankfm.pyx:329).  Epochs are
+    // enqueued without waiting; every kCheckEvery epochs the host looks at the flags the tail kernels have written so far
+    // (one 4-byte read-back) and stops launching once one is set, instead of training on NaN for the rest of the call.
+    constexpr int kCheckEvery = 8;
+    int epochs_launched = 0;
 
     for (int e = 0; e < E; ++e) {
+        if (cfg->check_finite && e > 0 && e % kCheckEvery == 0) {
+            std::vector<unsigned int> seen((size_t)e);
+            unsigned int err = 0;
+            RFM_HIP(hipMemcpyAsync(seen.data(), ws.nonfinite, sizeof(unsigned int) * e, hipMemcpyDeviceToHost, stream));
+            RFM_HIP(hipMemcpyAsync(&err, ws.error_flags, sizeof err, hipMemcpyDeviceToHost, stream));
+            RFM_HIP(hipStreamSynchronize(stream));
+            bool stop = (err & 3u) != 0;
+            for (unsigned int f : seen) stop |= f != 0;
+            if (stop) break;
+        }
+        epochs_launched = e + 1;
         const int epoch = cfg->epoch_begin + e;
         SgdArgs a;
         a.interactions = b->interactions; a.sample_weight = b->sample_weight;
@@ -529,7 +560,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.n_rows = N; a.n_items = cfg->n_items; a.n_uf = cfg->n_user_features; a.n_if = cfg->n_item_features;
         a.n_factors = cfg->n_factors; a.has_uf = cfg->has_user_features; a.has_if = cfg->has_item_features;
         a.max_samples = cfg->max_samples; a.rng = cfg->rng;
-        a.epoch_key = rfm_epoch_key(cfg->seed, (uint32_t)epoch);
+        a.epoch_key = rfm_epoch_key(cfg->seed, (uint32_t)(epoch + cfg->rng_epoch_offset));
         a.perm_bits = rfm_perm_bits((uint32_t)N);
         a.sw_csr = ws.sw_csr; a.seg_desc = ws.seg_desc; a.n_segments = n_segments;
         a.seg_bits = rfm_perm_bits((uint32_t)(n_segments > 0 ? n_segments : 1));
@@ -623,7 +654,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     int status = RFM_OK;
     int epochs_done = E, bad_array = -1;
     if (h_err[0] & 3u) status = RFM_ERR_USER_SATURATED;
-    for (int e = 0; e < E && status == RFM_OK; ++e) {
+    for (int e = 0; e < epochs_launched && status == RFM_OK; ++e) {
         if (cfg->check_finite && h_nonfinite[e]) {
             for (int k = 0; k < 6; ++k)
                 if (h_nonfinite[e] & (1u << k)) { bad_array = k; break; }    // first in assert_finite order
@@ -641,7 +672,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             }
             if (timing) {
                 float ms = 0.0f;
-                (void)hipEventElapsedTime(&ms, ev[2 * e], ev[2 * e + 1]);
+                if (e < epochs_launched) (void)hipEventElapsedTime(&ms, ev[2 * e], ev[2 * e + 1]);
                 rep->sgd_kernel_ms[e] = ms;
             }
         }
@@ -651,8 +682,6 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->waves_per_launch = single_group ? 1 : grid * waves_per_block;
         rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40)) : kRowsPlan);
     }
-    if (timing)
-        for (auto &e : ev) (void)hipEventDestroy(e);
     return status;
 }
 

@@ -65,9 +65,11 @@ class DeviceSession:
         self.hogwild_damping = float(hogwild_damping)
         self._plan_token = 0
         self.debug_flags = int(debug_flags)
+        self._geometry = None
 
-    def _config(self, epochs, epoch_begin, part=None):
+    def _config(self, epochs, epoch_begin, part=None, rng_epoch_offset=0):
         return _hip.FitConfig(
+            rng_epoch_offset=int(rng_epoch_offset),
             epoch_part_index=part[0] if part else 0, epoch_parts=part[1] if part else 0,
             hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token), debug_flags=self.debug_flags,
             debug_update_mode=self.update_mode, debug_shape=self.shape_override,
@@ -78,9 +80,9 @@ class DeviceSession:
             check_finite=self.check_finite, want_penalty=self.want_penalty,
             n_workgroups=self.n_workgroups, rows_per_launch=self.rows_per_launch, **self.hyper)
 
-    def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True, part=None):
+    def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True, part=None, rng_epoch_offset=0):
         """train `epochs` epochs in place on the resident tensors; returns the per-epoch report (numpy arrays)"""
-        cfg = self._config(epochs, epoch_begin, part)    # part = (k, n): only the k-th of n slices of each epoch's order
+        cfg = self._config(epochs, epoch_begin, part, rng_epoch_offset)    # part = (k, n): only the k-th of n slices of each epoch's order
         need = _hip.lib().rfm_fit_workspace_bytes(C.byref(cfg))
         if need == 0:
             _hip.raise_for_status(_hip.lib().rfm_fit_supported(C.byref(cfg)))
@@ -118,6 +120,10 @@ class DeviceSession:
         if raise_on_error:
             _hip.raise_for_status(rc)
         return out
+
+    def geometry(self):
+        """launch geometry of the last run (what rankfm_amd.order needs to mirror the engine's draws on the host)"""
+        return self._geometry
 
     def weights_to_host(self):
         return {k: v.detach().cpu().numpy() for k, v in self.weights.items()}

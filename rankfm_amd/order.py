@@ -77,3 +77,9 @@ def epoch_positions(csr_offsets, seed, epoch):
     bits = np.array([perm_bits(int(v)) for v in range(SEGMENT_ROWS + 1)], dtype=np.uint64)[lr]
     within = perm(t, lr, bits, np.repeat(seg_key, l))
     return np.repeat(b, l) + within
+
+
+def oracle_stripes(csr_offsets, seed, epoch, geometry):
+    """extra keyword arguments for oracle.fit that make the sequential oracle draw its negatives exactly like the launch
+    described by `geometry` (DeviceSession.geometry()); {} when the engine draws over the whole catalogue"""
+    return {}

@@ -201,12 +201,13 @@ class RankFM():
             raise ValueError('[loss] function not recognized')
 
         report = {}
-        # the reference's schedule restarts at epoch 0 on every call (rankfm/_rankfm.pyx:218-223): keep that for eta,
-        # but key the counter RNG by the absolute epoch so resumed training does not replay its draws
+        # the reference's schedule restarts at epoch 0 on every call (rankfm/_rankfm.pyx:218-223): keep that for eta
+        # (epoch_begin stays 0), but key the counter RNG and the keyed order by the absolute epoch so that resumed
+        # training with a fixed engine seed does not replay the first call's order and draws
         _fit(self.interactions, self.sample_weight, self.user_items, self.x_uf, self.x_if,
              self.w_i, self.w_if, self.v_u, self.v_i, self.v_uf, self.v_if,
              self.alpha, self.beta, self.learning_rate, self.learning_schedule, self.learning_exponent,
-             max_samples, epochs, verbose, engine=self.engine, report=report)
+             max_samples, epochs, verbose, engine=self.engine, rng_epoch_offset=self.epochs_trained, report=report)
         self.last_fit_report = report
         self.epochs_trained += epochs
         self.is_fit = True

@@ -4,6 +4,8 @@ u ~ Uniform{0..U-1}; i ~ Zipf-like (popularity exponent `zipf_s`) over a random 
 zipf_s == 0; (u, i) pairs de-duplicated and topped up to exactly N; ids are already 0-based int32 indexes;
 sample_weight = 1.  Everything is generated from seeds, so the GPU box needs no data files.
 """
+import os
+
 import numpy as np
 
 from ._rankfm import UserItemsCSR
@@ -13,24 +15,27 @@ CONFIGS = {
     "C1": dict(n_users=6040, n_items=3706, n_interactions=1_000_000, factors=20, loss="bpr", max_samples=1),
     "C2": dict(n_users=100_000, n_items=50_000, n_interactions=5_000_000, factors=64, loss="bpr", max_samples=1),
     "C3": dict(n_users=100_000, n_items=50_000, n_interactions=5_000_000, factors=64, loss="warp", max_samples=50),
+    # learning_rate 0.03: on 32 + 32 dense Bernoulli(0.25) tags the REFERENCE ALGORITHM ITSELF diverges at its default 0.1
+    # ("[w_i] are not finite" from the sequential oracle within one epoch; stable at <= 0.05)
     "C4": dict(n_users=1_000_000, n_items=200_000, n_interactions=50_000_000, factors=64, loss="bpr", max_samples=1,
-               n_user_features=32, n_item_features=32),
+               n_user_features=32, n_item_features=32, learning_rate=0.03),
     # not in BASELINE.json: config 4's feature setting at config 2's size (single-GPU feature-path measurements)
     "C4S": dict(n_users=100_000, n_items=50_000, n_interactions=5_000_000, factors=64, loss="bpr", max_samples=1,
-                n_user_features=32, n_item_features=32),
+                n_user_features=32, n_item_features=32, learning_rate=0.03),
     "C5": dict(n_users=5_000_000, n_items=1_000_000, n_interactions=500_000_000, factors=128, loss="warp", max_samples=50),
 }
 
 
-def make_interactions(n_users, n_items, n_interactions, seed=0, zipf_s=1.0):
-    """int32 [N,2] unique (user, item) pairs in random order, and the users' CSR item lists"""
+def make_interactions(n_users, n_items, n_interactions, seed=0, zipf_s=1.0, item_seed=None):
+    """int32 [N,2] unique (user, item) pairs in random order, and the users' CSR item lists.  `item_seed` fixes the
+    popularity ranking of the items independently of `seed` (user blocks of one data set share the catalogue)."""
     if n_interactions > n_users * (n_items - 1):
         raise ValueError("too dense: every user needs at least one unobserved item")
     rng = np.random.default_rng(seed)
     if zipf_s > 0:
         pop = 1.0 / np.power(np.arange(1, n_items + 1, dtype=np.float64), zipf_s)
         cdf = np.cumsum(pop / pop.sum())
-        item_of_rank = rng.permutation(n_items)
+        item_of_rank = (rng if item_seed is None else np.random.default_rng(item_seed)).permutation(n_items)
     keys = np.zeros(0, dtype=np.int64)
     while len(keys) < n_interactions:
         want = int((n_interactions - len(keys)) * 1.25) + 1024
@@ -51,6 +56,64 @@ def make_interactions(n_users, n_items, n_interactions, seed=0, zipf_s=1.0):
     pairs[:, 1] = keys % n_items
     csr = UserItemsCSR.from_pairs(pairs[:, 0], pairs[:, 1], n_users)
     return pairs, csr
+
+
+# ---- one data set per BASELINE config, defined block-wise so that a rank can generate exactly its own user shard ----
+# A config's data set is the union of USER_BLOCKS user blocks: block b holds users [b U/64, (b+1) U/64) with N/64 interactions
+# drawn like make_interactions over the SHARED item catalogue (one popularity ranking, `item_seed`).  Every block has the same
+# number of interactions, so the interaction-balanced user split of distributed.shard_boundaries falls on block boundaries for
+# world sizes dividing 64: rank r of W owns blocks [64 r / W, 64 (r+1) / W).  Config 5 (500 M interactions) can therefore be
+# sharded over 8 GPUs without any process ever materialising the whole data set.
+USER_BLOCKS = 64
+
+
+def config_shard_blocks(rank, world, n_blocks=USER_BLOCKS):
+    if n_blocks % world:
+        raise ValueError("world size must divide %d" % n_blocks)
+    per = n_blocks // world
+    return range(rank * per, (rank + 1) * per)
+
+
+def make_config_shard(name, rank=0, world=1, zipf_s=1.0, data_seed=0, init_seed=1492, blocks=None):
+    """the user shard `rank` of `world` of BASELINE config `name` (user indexes rebased to the shard): dict with
+    interactions, sample_weight, csr_offsets, csr_items, x_uf, x_if (whole catalogue), weights (v_u of the shard + the
+    item-side tables, identical on every rank), user_lo, user_hi"""
+    cfg = CONFIGS[name]
+    U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
+    P, Q = cfg.get("n_user_features", 0), cfg.get("n_item_features", 0)
+    blocks = list(config_shard_blocks(rank, world) if blocks is None else blocks)
+    # RFM_DATA_CACHE=<dir>: keep generated shards on disk (profiling scripts start bench.py many times on the same data)
+    cache = os.environ.get("RFM_DATA_CACHE", "")
+    cpath = os.path.join(cache, "%s_b%d-%d_z%g_d%d_i%d.npz" % (name, blocks[0], blocks[-1], zipf_s, data_seed, init_seed)) if cache else ""
+    if cpath and os.path.exists(cpath):
+        z = np.load(cpath)
+        out = {k: z[k] for k in z.files if not k.startswith("w__")}
+        out["weights"] = {k[3:]: z[k] for k in z.files if k.startswith("w__")}
+        out.update(user_lo=int(out["user_lo"]), user_hi=int(out["user_hi"]), config=cfg)
+        return out
+    ub, nb = U // USER_BLOCKS, N // USER_BLOCKS
+    pairs, items, offs, vus, xus = [], [], [np.zeros(1, np.int64)], [], []
+    for k, b in enumerate(blocks):
+        p, csr = make_interactions(ub, I, nb, seed=[data_seed, 1 + b], zipf_s=zipf_s, item_seed=[data_seed, 0])
+        p[:, 0] += k * ub
+        pairs.append(p)
+        items.append(csr.items)
+        offs.append(csr.offsets[1:] + k * nb)
+        vus.append(np.random.default_rng([init_seed, 1 + b]).normal(0, 0.1, (ub, F)).astype(np.float32))
+        if P:
+            xus.append(make_features(ub, P, [data_seed, 100 + b]))
+    n_local = ub * len(blocks)
+    w = init_weights(1, I, F, P, Q, seed=[init_seed, 0])
+    w["v_u"] = np.concatenate(vus)
+    pairs = np.concatenate(pairs)
+    out = dict(interactions=pairs, sample_weight=np.ones(len(pairs), np.float32), csr_offsets=np.concatenate(offs),
+               csr_items=np.concatenate(items), x_uf=np.concatenate(xus) if P else np.zeros((n_local, 1), np.float32),
+               x_if=make_features(I, Q, [data_seed, 99]) if Q else np.zeros((I, 1), np.float32), weights=w,
+               user_lo=blocks[0] * ub, user_hi=(blocks[-1] + 1) * ub, config=cfg)
+    if cpath:
+        os.makedirs(cache, exist_ok=True)
+        np.savez(cpath, **{k: v for k, v in out.items() if k not in ("weights", "config")}, **{"w__" + k: v for k, v in w.items()})
+    return out
 
 
 def make_features(n_rows, n_features, seed, density=0.25):

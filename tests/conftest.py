@@ -31,3 +31,13 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture(scope="session")
+def c2_problem():
+    """BASELINE.json config 2 / 3 data at full size (seeded): 100 k users x 50 k items x 5 M interactions"""
+    from rankfm_amd import synthetic
+    cfg = synthetic.CONFIGS["C2"]
+    U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=0)
+    return U, I, N, F, pairs, csr

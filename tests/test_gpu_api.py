@@ -43,6 +43,35 @@ def test_fit_partial_and_sample_weight():
     assert len(m.interactions) == 5 and m.user_items[0].tolist() == [0, 2, 4]
 
 
+def test_resumed_fit_with_a_fixed_seed_does_not_replay_order_and_draws():
+    """fit_partial keys the counter RNG and the keyed order by the epochs already trained (rfm_fit_config.rng_epoch_offset)
+    while the learning-rate schedule restarts at 0 like the reference's (rankfm/_rankfm.pyx:218-223): from identical weights,
+    a second call must take a different trajectory than the first, and exactly the one of `_fit(..., rng_epoch_offset=1)`.
+    Single-group mode, so both runs are deterministic."""
+    from rankfm_amd import EngineOptions, RankFM, synthetic
+    from rankfm_amd._rankfm import _fit
+    d = synthetic.make_planted(300, 200, seed=1, mean_degree=30.0)
+    train = pd.DataFrame(d["train"], columns=["u", "i"])
+    eng = EngineOptions(seed=5, debug_flags=1)
+    m = RankFM(factors=8, learning_schedule="invscaling", engine=eng)
+    np.random.seed(0)
+    m._init_all(train)
+    init = {k: getattr(m, k).copy() for k in WEIGHTS}
+    m.fit_partial(train, epochs=1)
+    first = {k: getattr(m, k).copy() for k in WEIGHTS}
+    assert m.epochs_trained == 1
+    for k in WEIGHTS:
+        getattr(m, k)[...] = init[k]
+    m.fit_partial(train, epochs=1)                                   # same weights, same data, same seed: second call
+    second = {k: getattr(m, k).copy() for k in WEIGHTS}
+    assert not np.allclose(first["v_i"], second["v_i"], atol=1e-4)    # ... is not a replay of the first
+    w = {k: v.copy() for k, v in init.items()}
+    _fit(m.interactions, m.sample_weight, m.user_items, m.x_uf, m.x_if, w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"],
+         m.alpha, m.beta, m.learning_rate, m.learning_schedule, m.learning_exponent, 1, 1, False, engine=eng, rng_epoch_offset=1)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(second[k], w[k], rtol=1e-6, atol=1e-7)
+
+
 def test_predict_shapes_dtypes_and_cold_start():
     m = _model().fit(INTX)
     s = m.predict(INTX)

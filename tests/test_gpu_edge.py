@@ -147,3 +147,26 @@ def test_epoch_parts_compose_to_the_whole_epoch():
     assert draws == r0["n_draws"][0] == len(pairs) and ll == pytest.approx(r0["log_likelihood"][0], rel=1e-9)
     with pytest.raises(ValueError):
         sliced.run(epochs=1, part=(5, 5))
+
+
+def test_duplicate_heavy_user_with_more_rows_than_items_trains(oracle):
+    """A user with 60 rows over 20 DISTINCT items of a 50-item catalogue is not saturated: the reference's rejection sampler
+    terminates on such data (rankfm/_rankfm.pyx:250-253) and so must the engine -- the saturation guard counts distinct
+    items, not rows.  A user who really holds every item (with duplicates on top) is still refused."""
+    rng = np.random.default_rng(3)
+    heavy = np.stack([np.zeros(60, np.int64), rng.integers(0, 20, 60)], 1)
+    heavy[:20, 1] = np.arange(20)                                       # all 20 items present
+    rest = np.stack([rng.integers(1, 25, 400), rng.integers(0, 50, 400)], 1)
+    pairs = np.concatenate([heavy, rest]).astype(np.int32)
+    key = pairs[:, 0].astype(np.int64) * 1000 + pairs[:, 1]
+    sw = np.ones(len(pairs), np.float32)
+    csr = _csr(pairs, 25)
+    assert csr.offsets[1] - csr.offsets[0] == 60 and len(np.unique(csr[0])) == 20
+    g, rep, o, out = _run(pairs, csr, sw, 16, 1, 2, 5, dict(debug_flags=1), oracle)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg=k)
+    g, rep, o, out = _run(pairs, csr, sw, 16, 1, 2, 5, {}, oracle)       # and as a Hogwild run
+    assert np.isfinite(rep["log_likelihood"]).all() and rep["n_draws"][0] == len(pairs)
+    full = np.concatenate([np.stack([np.zeros(70, np.int64), np.concatenate([np.arange(50), rng.integers(0, 50, 20)])], 1), rest]).astype(np.int32)
+    with pytest.raises(ValueError, match="every item"):
+        _run(full, _csr(full, 25), np.ones(len(full), np.float32), 16, 1, 1, 5, {}, oracle)

@@ -227,16 +227,6 @@ def test_ranking_quality_matches_oracle_on_planted_data(oracle):
     np.testing.assert_allclose(np.mean(norms["gpu"], axis=0), np.mean(norms["oracle"], axis=0), rtol=0.02)
 
 
-@pytest.fixture(scope="module")
-def c2_problem():
-    """BASELINE.json config 2 at full size (seeded)"""
-    from rankfm_amd import synthetic
-    cfg = synthetic.CONFIGS["C2"]
-    U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
-    pairs, csr = synthetic.make_interactions(U, I, N, seed=0)
-    return U, I, N, F, pairs, csr
-
-
 def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
     """BASELINE config 2 at FULL size, default (full-chip) concurrency: two epochs of Hogwild on the GPU against two
     epochs of the sequential CPU oracle on the same counter-based draws and visiting order.  Norms within 2 %,
