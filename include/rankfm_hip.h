@@ -102,7 +102,8 @@ typedef struct rfm_fit_config {
     int32_t debug_shape;           /* experiments: 1-based index into the kernel shape table, 0 = automatic */
     int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
                                       bit 1: factor-row loads bypass the per-CU L1,
-                                      bit 2: no LDS accumulation of hot item rows */
+                                      bit 2: no LDS accumulation of hot item rows,
+                                      bit 3: no negative stripes (draws over the whole catalogue, atomics per negative) */
     int32_t epoch_part_index;      /* with epoch_parts > 1: run only part k (0-based) of each epoch's visiting order -- lets a */
     int32_t epoch_parts;           /* multi-GPU caller exchange item deltas several times per epoch; 0 or 1 = whole epochs    */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
@@ -142,6 +143,14 @@ typedef struct rfm_fit_report {
     int32_t launches_per_epoch;
     int32_t waves_per_launch;
     int64_t plan_token;            /* pass back as rfm_fit_config.plan_token to reuse the plan held in `workspace` */
+    /* launch geometry of the Hogwild kernel: what a host program needs to replay the engine's draws (rankfm_amd/order.py) */
+    int32_t workgroups;            /* grid size */
+    int32_t groups_per_workgroup;  /* row groups (one interaction each) per workgroup */
+    int64_t working_groups;        /* row groups that work (the concurrency cap can be below the grid's capacity) */
+    int64_t units_per_launch;      /* user segments (or rows) per launch */
+    int64_t n_units;               /* user segments (or rows) per epoch */
+    int32_t stripe_rows;           /* items per negative stripe (include/rfm_rng.h), 0 = draws over the whole catalogue */
+    int32_t stripe_window;         /* rows per group between stripe changes */
 } rfm_fit_report;
 
 int rfm_abi_version(void);

@@ -34,6 +34,7 @@ class OracleParams(C.Structure):
         ("rng_mode", C.c_int32),
         ("seed", C.c_uint32),
         ("membership", C.c_int32),
+        ("stripe_rows", C.c_int32),
     ]
 
 
@@ -87,7 +88,7 @@ def mt_stream(seed, n):
 def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
         alpha, beta, learning_rate, learning_schedule, learning_exponent, max_samples, epochs,
         perms=None, rng_mode=RNG_MT19937, seed=REFERENCE_MT_SEED, epoch_begin=0, membership="linear",
-        has_uf=None, has_if=None, want_negatives=False):
+        has_uf=None, has_if=None, want_negatives=False, row_stripe=None, stripe_rows=0):
     """Run the sequential restatement of `_fit` IN PLACE on the six weight arrays.
 
     Returns dict(ll=float64[epochs], neg=int32[epochs,N] | None, nsamp=int32[epochs,N] | None).
@@ -110,7 +111,10 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
         schedule=0 if learning_schedule == "constant" else 1,
         learning_exponent=learning_exponent, max_samples=max_samples,
         epochs=epochs, epoch_begin=epoch_begin, rng_mode=rng_mode, seed=seed,
-        membership=0 if membership == "linear" else 1)
+        membership=0 if membership == "linear" else 1, stripe_rows=int(stripe_rows))
+    if row_stripe is not None:
+        row_stripe = np.ascontiguousarray(row_stripe, dtype=np.int32)
+        assert row_stripe.shape == (epochs, N) and rng_mode == RNG_COUNTER and stripe_rows >= 1
     if perms is not None:
         perms = np.ascontiguousarray(perms, dtype=np.int32)
         assert perms.shape == (epochs, N)
@@ -123,7 +127,7 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
         _p(_f32(x_uf), C.c_float), _p(_f32(x_if), C.c_float),
         _p(_f32(w_i), C.c_float), _p(_f32(w_if), C.c_float), _p(_f32(v_u), C.c_float),
         _p(_f32(v_i), C.c_float), _p(_f32(v_uf), C.c_float), _p(_f32(v_if), C.c_float),
-        _p(perms, C.c_int32), _p(ll, C.c_double), _p(neg, C.c_int32), _p(nsamp, C.c_int32))
+        _p(perms, C.c_int32), _p(ll, C.c_double), _p(neg, C.c_int32), _p(nsamp, C.c_int32), _p(row_stripe, C.c_int32))
     if rc >= 100:
         raise AssertionError("[%s] are not finite" % _ARRAY_NAMES[rc - 100])
     if rc != 0:

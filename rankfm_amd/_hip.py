@@ -57,7 +57,14 @@ class FitReport(C.Structure):
         ("epochs_done", C.c_int32), ("nonfinite_array", C.c_int32),
         ("launches_per_epoch", C.c_int32), ("waves_per_launch", C.c_int32),
         ("plan_token", C.c_int64),
+        ("workgroups", C.c_int32), ("groups_per_workgroup", C.c_int32), ("working_groups", C.c_int64),
+        ("units_per_launch", C.c_int64), ("n_units", C.c_int64), ("stripe_rows", C.c_int32), ("stripe_window", C.c_int32),
     ]
+
+    def geometry(self):
+        """launch geometry as a dict (rankfm_amd.order mirrors the engine's negative draws from it)"""
+        return {k: int(getattr(self, k)) for k in ("workgroups", "groups_per_workgroup", "working_groups", "units_per_launch",
+                                                   "n_units", "stripe_rows", "stripe_window", "launches_per_epoch")}
 
 
 class ModelView(C.Structure):

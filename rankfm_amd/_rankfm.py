@@ -227,7 +227,8 @@ def _fit(interactions, sample_weight, user_items, x_uf, x_if, w_i, w_if, v_u, v_
     if report is not None:
         report.update(log_likelihood=ll, reg_penalty=pen, sgd_kernel_ms=ms, n_draws=draws, seed=seed,
                       epochs_done=rep.epochs_done, launches_per_epoch=rep.launches_per_epoch,
-                      waves_per_launch=rep.waves_per_launch)
+                      waves_per_launch=rep.waves_per_launch,
+                      geometry=dict(rep.geometry(), single_group=bool(int(opt.debug_flags) & 1), seed=seed & 0xFFFFFFFF, epoch_part=None))
     _hip.raise_for_status(rc)
     return None
 

@@ -130,12 +130,15 @@ __global__ void degree_check_kernel(const int64_t *__restrict__ off, const int32
 // ---------------------------------------------------------------------------------------------
 constexpr int kBiasStride = 16;
 // item biases <-> their padded copy (SgdArgs::w_stride); PAD: w_pad[i * 16] = w_i[i], else the reverse
+// (dword 1 of an item's line carries its step scale pos_scale[i], so that bias and scale cost the SGD kernel one request)
 template <bool PAD>
-__global__ void bias_pad_kernel(float *__restrict__ w_i, float *__restrict__ w_pad, int n_items) {
+__global__ void bias_pad_kernel(float *__restrict__ w_i, float *__restrict__ w_pad, const float *__restrict__ pos_scale, int n_items) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
-    if (PAD) w_pad[(size_t)i * kBiasStride] = w_i[i];
-    else w_i[i] = w_pad[(size_t)i * kBiasStride];
+    if (PAD) {
+        w_pad[(size_t)i * kBiasStride] = w_i[i];
+        w_pad[(size_t)i * kBiasStride + 1] = pos_scale ? pos_scale[i] : 1.0f;
+    } else w_i[i] = w_pad[(size_t)i * kBiasStride];
 }
 
 __global__ void item_count_kernel(const int32_t *__restrict__ interactions, long long n, int *__restrict__ count) {
@@ -423,7 +426,24 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         n_hot = (int)hot_order.size();
     }
     const bool use_hot = use_segments && !feat && !single_group && n_hot > 0;
-    const sgd_launch_fn launch = use_hot ? shape->table()[8 + (fresh ? 1 : 0)]
+    // Negative stripes (rfm_sgd.hpp, STRIPE; include/rfm_rng.h): the production path without features.  debug_flags bit 3 (or
+    // RFM_NO_STRIPES, an experiment knob) falls back to whole-catalogue draws with one set of atomics per negative.
+    // BPR only: WARP's candidate screening inside a stripe (up to 50 draws WITH replacement from ~200 items) changes the
+    // statistics of the rank estimate -- against the sequential oracle the log-likelihood moved by -5 % at a 12-row window --
+    // and the WARP instantiation gained no time from it (it is bound by its register spills, not by the candidate reads);
+    // RFM_WARP_STRIPES=1 switches them on for experiments.
+    bool use_stripes = use_segments && !feat && !(cfg->debug_flags & 8) && !getenv("RFM_NO_STRIPES") &&
+                       (cfg->max_samples == 1 || getenv("RFM_WARP_STRIPES"));
+    // ... for launches that fill a good part of the chip: a few workgroups are nowhere near the atomic ceiling (their time is
+    // memory latency), and delayed publication only costs them accuracy.  (One group alone keeps the stripes: that is the
+    // sequential form of the production kernel the parity tests pin to the oracle.)  The grid is not known yet; estimate it
+    // from the same caps the geometry below applies.
+    if (use_stripes && !single_group && cfg->n_workgroups <= 0) {
+        const long long cap_groups = std::min<long long>(N / 128, (long long)std::min(cfg->n_users, cfg->n_items) / 3);
+        if (cap_groups < 32LL * 16 * (64 / shape->group)) use_stripes = false;
+    }
+    const sgd_launch_fn launch = use_stripes ? shape->table()[10 + (fresh ? 1 : 0) + (use_hot ? 2 : 0)]
+                                 : use_hot  ? shape->table()[8 + (fresh ? 1 : 0)]
                                  : use_segments ? shape->table()[4 + (feat ? 1 : 0) + (fresh ? 2 : 0)]
                                                 : shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
 
@@ -432,10 +452,20 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     const int groups_per_wave = serial ? 1 : 64 / shape->group;
     // feature instantiation: the largest workgroup (<= 16 wavefronts) whose table replica + staging area fit in LDS
     int feat_waves = 16;
+    if (getenv("RFM_FEAT_WAVES")) feat_waves = std::max(1, std::min(16, atoi(getenv("RFM_FEAT_WAVES"))));   // (experiment knob)
     if (use_segments && feat)
         while (feat_waves > 1 && feat_lds_bytes(cfg->n_user_features, cfg->n_item_features, cfg->n_factors,
                                                 feat_waves * 64 / shape->group) > kLdsBytes) feat_waves /= 2;
-    const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : (use_hot ? 16 : 4));   // see sgd_segments_kernel
+    const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : ((use_hot || use_stripes) ? 16 : 4));   // see sgd_segments_kernel
+    // stripe geometry: as many rows as the LDS left by the hot-row accumulators holds (at most 256: more rows mean longer
+    // windows for the same combining), and a window in which a stripe row receives ~8 updates (groups x window / rows)
+    int stripe_rows = 0, stripe_window = 1, stripe_rows_cap = 0;
+    if (use_stripes) {
+        const size_t budget = 156 * 1024 - sizeof(float) * (use_hot ? (size_t)n_hot * (cfg->n_factors + 2) : 0);
+        stripe_rows = (int)std::min<size_t>(256, (budget - sizeof(float) * ((size_t)cfg->n_factors + 1)) / (sizeof(float) * (1 + 2 * ((size_t)cfg->n_factors + 1))));
+        stripe_rows = std::max(1, std::min(stripe_rows, cfg->n_items));
+        stripe_rows_cap = stripe_rows;
+    }
     int grid = 1;
     int64_t max_groups = 0;
     int64_t units_per_launch = units > 0 ? units : 1;
@@ -477,10 +507,45 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             const int64_t groups = (int64_t)grid * groups_per_block;
             int64_t windows = units / (groups * 8);
             if (windows > 16) windows = 16;
+            if (getenv("RFM_FEAT_WINDOWS")) windows = std::max(1, atoi(getenv("RFM_FEAT_WINDOWS")));   // (experiment knob)
             if (windows > 1) units_per_launch = (units + windows - 1) / windows;
         }
     }
     const int launches = (int)((units + units_per_launch - 1) / units_per_launch);
+    if (use_stripes) {
+        // concurrent windows should hold DISJOINT stripes (then a stripe row's exact view misses nothing but in-flight
+        // updates): at least as many stripes as workgroups.  A window lets a stripe row combine ~10 updates into one
+        // publication (groups x window / rows), at most 32 rows per group.
+        const int gpb = waves_per_block * groups_per_wave;
+        // Window length.  A stripe row's updates stay in LDS until its window ends: at any time the last ~window / 2 rows of
+        // every working group are unpublished, (groups x window / 2) / I pending DOWNWARD pushes per item that the rest of the
+        // chip does not see.  What that costs depends on the view a step takes of its two items (profiles/r02_notes.md): if
+        // the negative is seen with the workgroup's own pending pushes while the positive -- whose pending pushes sit in some
+        // other workgroup's LDS -- is seen without them, every pairwise utility is overestimated and the log-likelihood
+        // drifts from the sequential oracle's in proportion to the window (config 2: -0.3 / -2.3 / -5.8 % at 8 / 16 / 32 rows);
+        // with BOTH items seen as published (RowStep::fetch_item) the staleness is symmetric and the log-likelihood no longer
+        // moves with the window (+1.7 / +1.6 / +1.7 %, +1.2 % without stripes), only the norms creep up (+0.5 -> +0.9 % on v_i)
+        // as several pushes of a window start from the same published value.  Window = 4 I / groups rows (<= 32): ~2 pending
+        // pushes per item; stripe = groups x window / 2 rows (<= 256): ~2-3 pushes per row and publication -- a smaller stripe
+        // would combine more (64 rows: 2.46 instead of 2.63 ms at window 8), but concentrates the pending pushes on fewer
+        // rows, and past that point the atomics no longer bound the kernel.
+        const long long g_work = single_group ? 1 : std::min<long long>((long long)grid * gpb, max_groups > 0 ? max_groups : (1LL << 60));
+        stripe_window = (int)std::max<long long>(1, std::min<long long>(32, (long long)(4.0 * (double)cfg->n_items / (double)g_work + 0.5)));
+        if (getenv("RFM_STRIPE_WINDOW")) stripe_window = std::max(1, atoi(getenv("RFM_STRIPE_WINDOW")));                     // (experiment knob)
+        if (single_group) stripe_window = 1;      // one group alone: a fresh stripe for every row keeps it exactly sequential
+        const int combine = getenv("RFM_STRIPE_COMBINE") ? std::max(1, atoi(getenv("RFM_STRIPE_COMBINE"))) : 2;             // (experiment knob)
+        int want_rows = std::max(16, (int)std::min<long long>(g_work, gpb) * stripe_window / combine);
+        if (getenv("RFM_STRIPE_ROWS")) want_rows = std::max(0, atoi(getenv("RFM_STRIPE_ROWS")));                            // (experiment knob)
+        stripe_rows = std::max(want_rows > 0 ? 1 : 0, std::min(std::min(stripe_rows_cap, want_rows), cfg->n_items / (single_group ? 1 : grid)));
+        // consecutive windows of one workgroup start grid x rows positions apart (include/rfm_rng.h): keep that step, taken
+        // around the cycle of I positions, at least a stripe long so that they do not overlap
+        if (!single_group && stripe_rows > 0 && cfg->n_items >= 2 * stripe_rows)
+            while (stripe_rows > 1) {
+                const long long step = ((long long)grid * stripe_rows) % cfg->n_items;
+                if (step >= stripe_rows && step <= cfg->n_items - stripe_rows) break;
+                --stripe_rows;
+            }
+    }
 
     // ---- plan, part 3: Hogwild damping.  n(row) = interactions in flight x the row's share of the data (+ what the other
     //      workgroups hold unpublished for a hot row); scale = min(1, M / n)
@@ -519,8 +584,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // and the caller read w_i)
     // (WARP reads a bias per candidate, ~20 per update: there the 16x larger table costs more in read misses than the
     // atomics gain -- config 3: 318 M updates/s unpadded, 306 M padded -- so only BPR-like sampling pads)
-    const bool pad_bias = !serial && cfg->max_samples <= 4 && !getenv("RFM_NO_BIAS_PAD");   // (experiment knob)
-    if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, cfg->n_items);
+    // (with stripes the candidates' biases are LDS reads, so WARP pads as well)
+    const bool pad_bias = !serial && (use_stripes || cfg->max_samples <= 4) && !getenv("RFM_NO_BIAS_PAD");   // (experiment knob)
+    if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, damp ? ws.pos_scale : nullptr, cfg->n_items);
     // timing events: destroyed on every exit path
     struct Events {
         std::vector<hipEvent_t> ev;
@@ -553,7 +619,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         SgdArgs a;
         a.interactions = b->interactions; a.sample_weight = b->sample_weight;
         a.csr_off = b->csr_offsets; a.csr_items = b->csr_items; a.x_uf = b->x_uf; a.x_if = b->x_if;
-        a.w_i = pad_bias ? ws.w_pad : b->w_i; a.w_stride = pad_bias ? kBiasStride : 1; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
+        a.w_i = pad_bias ? ws.w_pad : b->w_i; a.w_stride = pad_bias ? kBiasStride : 1; a.scale_in_pad = pad_bias && damp ? 1 : 0; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
         a.perm = b->perms ? b->perms + (size_t)e * N : nullptr;
         a.multiplier = ws.multiplier; a.mt_state = ws.mt_state;
         a.ll = ws.ll + e; a.draws = ws.draws + e; a.error_flags = ws.error_flags;
@@ -569,6 +635,14 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
         a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w; a.sw_max_bits = ws.sw_max_bits;
         a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * grid ? 1 : 0;   // see SgdArgs::hot_bins_v
+        a.stripe_rows = stripe_rows; a.stripe_window = stripe_window;
+        a.item_bits = rfm_perm_bits((uint32_t)cfg->n_items);
+        a.launch_index = 0;
+        a.stripe_own = getenv("RFM_STRIPE_OWN") ? atoi(getenv("RFM_STRIPE_OWN")) : 1;   // (experiment knob)
+        a.stripe_bias_direct = getenv("RFM_STRIPE_BIAS") ? atoi(getenv("RFM_STRIPE_BIAS")) : 0;   // (experiment knob)
+        a.stripe_cover = stripe_rows > 0 ? std::min(1.0f, (float)grid * (float)stripe_rows / (float)cfg->n_items) : 0.0f;
+        a.stripe_mean = getenv("RFM_STRIPE_MEAN") ? atoi(getenv("RFM_STRIPE_MEAN")) : 1;   // (experiment knob)
+        a.stripe_exact = getenv("RFM_STRIPE_EXACT") ? atoi(getenv("RFM_STRIPE_EXACT")) : 1;   // (experiment knob)
         a.feat_snapshot = ws.feat_snapshot;
         a.feat_merge = 1.0f / (float)grid;
         a.block_threads = waves_per_block * 64;
@@ -590,7 +664,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         // merge rule of the LDS feature replicas: a replica trains on ~rows_per_window / workgroups interactions; if that is
         // several times the tables' memory 1 / (2 * beta * eta), take one replica (rotating), else average them
         const double rows_per_replica = (double)N / (double)launches / (double)(grid > 0 ? grid : 1);
-        const bool select_replica = rows_per_replica * (double)a.eta * (double)a.reg_b >= 4.0;
+        bool select_replica = rows_per_replica * (double)a.eta * (double)a.reg_b >= 4.0;
+        if (getenv("RFM_FEAT_MERGE")) select_replica = atoi(getenv("RFM_FEAT_MERGE")) == 0;   // (experiment knob: 0 select, 1 average)
         int window = 0;
         // a caller may ask for one part of the epoch's order only (several delta exchanges per epoch on multi-GPU jobs)
         int64_t u_begin = 0, u_end = units;
@@ -600,6 +675,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         }
         for (int64_t p0 = u_begin; p0 < u_end; p0 += units_per_launch, ++window) {
             a.feat_select_wg = (use_segments && feat && select_replica) ? (int)((e * launches + window) % grid) : -1;
+            a.launch_index = (uint32_t)window;
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
             if (use_segments && feat) {      // the replicas start from, and are merged against, the tables as of now
@@ -610,7 +686,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             }
             launch(a, grid, stream);
         }
-        if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, cfg->n_items);
+        if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));
 
         if (cfg->check_finite || cfg->want_penalty) {
@@ -680,6 +756,14 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->nonfinite_array = bad_array;
         rep->launches_per_epoch = launches;
         rep->waves_per_launch = single_group ? 1 : grid * waves_per_block;
+        rep->workgroups = grid;
+        rep->groups_per_workgroup = single_group ? 1 : waves_per_block * groups_per_wave;
+        rep->working_groups = single_group ? 1 : ((max_groups > 0 && max_groups < (int64_t)grid * waves_per_block * groups_per_wave)
+                                                      ? max_groups : (int64_t)grid * waves_per_block * groups_per_wave);
+        rep->units_per_launch = units_per_launch;
+        rep->n_units = units;
+        rep->stripe_rows = stripe_rows;
+        rep->stripe_window = stripe_window;
         rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40)) : kRowsPlan);
     }
     return status;

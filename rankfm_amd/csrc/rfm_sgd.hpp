@@ -47,6 +47,7 @@ struct SgdArgs {
     // update collide on ~3000 lines and retire serially memory-side: they cost as much as the four atomics of an item
     // row (measured on config 2, uniform items: 2.88 ms with, 2.37 ms without the bias atomics).
     int32_t w_stride;
+    int32_t scale_in_pad;                       // 1: dword 1 of an item's padded bias line holds pos_scale[item] (one request for both)
     const int32_t *__restrict__ perm;           // this epoch's visiting order [N] or nullptr        (rows kernel)
     const float *__restrict__ sw_csr;           // [N] sample weight by CSR position                 (segments kernel)
     const int4 *__restrict__ seg_desc;          // [S] {user, first CSR position, length, 0}         (segments kernel)
@@ -109,6 +110,15 @@ struct SgdArgs {
     float *hot_bins_w;                          // [kHotBins, n_hot]
     int32_t hot_direct;
     const unsigned int *sw_max_bits;            // bits of max |sample_weight| (plan): range of the fixed-point hot sums
+    // negative stripes (segments kernel, STRIPE instantiation; include/rfm_rng.h "negative stripes"): the workgroup draws the
+    // negatives of a window of `stripe_window` rows per group from `stripe_rows` items whose rows it holds in LDS
+    int32_t stripe_rows, stripe_window;
+    uint32_t item_bits, launch_index;
+    int32_t stripe_own;                         // experiment: 1 = a stripe row's value includes the workgroup's own pending sum
+    int32_t stripe_bias_direct;                 // 1 = the negative's BIAS step is published at once (one atomic), only its factor row waits
+    float stripe_cover;                         // share of the catalogue that sits in some workgroup's stripe at any time, <= 1
+    int32_t stripe_mean;                        // 1 = the positive item's view includes the stripe's MEAN pending sum (see RowStep::sn_sum)
+    int32_t stripe_exact;                       // 1 = the stepped negative is re-read from memory (+ own pending sum), 0 = snapshot
 };
 constexpr int kHotBins = 16;
 
@@ -117,6 +127,8 @@ inline size_t feat_lds_bytes(int n_uf, int n_if, int n_factors, int groups) {
     return sizeof(float) * ((size_t)(n_uf + n_if) * n_factors + n_if + 2 * (size_t)groups * (3 + 2 * (size_t)n_factors + n_uf + n_if));
 }
 constexpr size_t kLdsBytes = 160 * 1024;        // per workgroup on gfx950
+// LDS floats of a negative stripe of R rows: [R] items | [R, F+1] snapshot | [R, F+1] pending sums | [F+1] their column sums
+inline size_t stripe_lds_floats(int rows, int n_factors) { return (size_t)rows * (1 + 2 * ((size_t)n_factors + 1)) + (size_t)n_factors + 1; }
 
 constexpr float kMargin = 1.0f;                 // rankfm/_rankfm.pyx:149
 constexpr uint32_t kMaxAttempts = 1u << 22;     // safety net; the host rejects saturated users up front
@@ -125,10 +137,29 @@ constexpr int kSegmentRows = 32;                // longest user segment (host pl
 // ---------------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------------
+// All-reduce over the G lanes of a row group; every lane ends with the bit-identical sum (the WARP control flow relies on
+// it).  Inside a 16-lane row the partner values come through DPP row rotations -- plain VALU operands, no LDS round trip
+// (a ds_bpermute-based butterfly is four dependent ~100-clock LDS accesses per dot product, and a WARP row computes ~20 of them:
+// the candidate scoring loop was bound by exactly that latency chain).  Rotation by 8, 4, 2, 1 pairs the same lanes as the xor
+// butterfly (after the first step the partial sums have period 8, and so on), so the result is the butterfly's, bit for bit.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
 template <int G>
 __device__ __forceinline__ float group_sum(float x) {
+    if constexpr (G >= 16) {
+        x += dpp_mov<0x128>(x);      // row_ror:8
+        x += dpp_mov<0x124>(x);      // row_ror:4
+        x += dpp_mov<0x122>(x);      // row_ror:2
+        x += dpp_mov<0x121>(x);      // row_ror:1
 #pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) x += __shfl_xor(x, m);
+        for (int m = 16; m < G; m <<= 1) x += __shfl_xor(x, m);
+    } else {
+        static_assert(G == 4, "row groups are 4, 16 or 64 lanes");
+        x += dpp_mov<0x4E>(x);       // quad_perm:[2,3,0,1]
+        x += dpp_mov<0xB1>(x);       // quad_perm:[1,0,3,2]
+    }
     return x;
 }
 
@@ -267,7 +298,10 @@ __device__ __forceinline__ float log_sigmoid(float x) {
 //   LDSF     the dense feature tables (v_uf, v_if, w_if) are this workgroup's LDS replica: plain step size, LDS atomics
 //   HOT      updates of hot positive items are accumulated in the workgroup's LDS and published every few touches
 //   WARPB    compile the batched WARP draw loop (max_samples > 1); the BPR instantiation stays at ~76 VGPRs without it
-template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false, bool WARPB = true>
+//   STRIPE   negatives come from the workgroup's LDS stripe: candidate rows are read from, and the negative's update is added
+//            to, LDS (snapshot + fixed-point pending delta); the user's item list is tested from registers when it is short
+template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false, bool WARPB = true,
+          bool STRIPE = false>
 struct RowStep {
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
@@ -292,6 +326,105 @@ struct RowStep {
     }
     __device__ __forceinline__ float hot_take(lds_int *p) const {
         return (float)__hip_atomic_exchange(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * kHotUnit;
+    }
+
+    // negative stripe (STRIPE): [R] item of each row | [R, F+1] fp32 snapshot of v_i[item] and (last column) w_i[item] at window
+    // start | [R, F+1] pending updates in the same 32-bit fixed point as the hot sums.  A row's value is snapshot + pending.
+    lds_int *sn_item = nullptr;
+    lds_float *sn_snap = nullptr;
+    lds_int *sn_delta = nullptr;
+    // [F+1] column sums of sn_delta.  The positive item of a step sits, with probability stripe_cover, in some other
+    // workgroup's stripe and then carries pending pushes this workgroup cannot see; the workgroups run their windows in step
+    // and stripes are uniform samples of the items, so the MEAN pending sum of this workgroup's own stripe rows (x the cover)
+    // is what such an item is expected to carry.  Negative: published + own pending sum (exact, sequential inside the
+    // workgroup); positive: published + expected pending sum.  Without the correction every pairwise utility is
+    // overestimated by the positive's unseen downward pushes (log-likelihood -6 % against the sequential oracle at a 32-row
+    // window on config 2; with it +0.1 %, profiles/r02_notes.md).
+    lds_int *sn_sum = nullptr;
+    float sn_inv_rows = 0.0f;
+    int sn_rows = 0;
+    // the user's sorted item list, held across the lanes when it has at most 4 G entries (lane s: entries s, s+G, ...; -1 pads):
+    // the membership test of a draw is then four compares and a ballot instead of a memory round trip
+    int32_t ulist[4] = {-1, -1, -1, -1};
+    bool ulist_ok = false;
+    __device__ __forceinline__ void load_ulist(int64_t lo, int64_t hi) {
+        ulist_ok = (hi - lo) <= 4 * G;
+        if (ulist_ok) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t idx = lo + sub + (int64_t)G * k;
+                ulist[k] = idx < hi ? a.csr_items[idx] : -1;
+            }
+        }
+    }
+    __device__ __forceinline__ bool member(int64_t lo, int64_t hi, int32_t item) const {
+        if (ulist_ok) {
+            const bool f = (ulist[0] == item) | (ulist[1] == item) | (ulist[2] == item) | (ulist[3] == item);
+            if constexpr (G == 64) return __ballot(f) != 0ull;
+            else return group_ballot<G>(f) != 0u;
+        }
+        return is_member_group<G>(a.csr_items, lo, hi, item, sub);
+    }
+    __device__ __forceinline__ void members4(int64_t lo, int64_t hi, const int32_t (&c)[4], bool (&m)[4]) const {
+        if (ulist_ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m[q] = member(lo, hi, c[q]);
+        } else {
+            members4_group<G>(a.csr_items, lo, hi, c, m, sub);
+        }
+    }
+    // factor row + bias of item `it`.  An item of the workgroup's stripe (row `srow` >= 0) has two views:
+    //   screening (fresh = false): the snapshot taken when the window started -- an LDS read; WARP examines ~20 candidates per
+    //       update this way;
+    //   published (fresh = true): memory as of now (L1 bypassed) -- everything every workgroup has published, like the view
+    //       every step has of its POSITIVE item.  Used for the negative that is actually stepped.
+    // Neither includes the workgroup's own pending sum of the row (SgdArgs::stripe_own = 0): the positive item's pending
+    // pushes sit unseen in some other workgroup's LDS, and a step that saw its negative's pending pushes but not its
+    // positive's would overestimate every pairwise utility (measured: log-likelihood -6 % against the sequential oracle at a
+    // 32-row window, profiles/r02_notes.md).  Seen alike, the two stale views cancel in the pairwise difference.
+    __device__ __forceinline__ void fetch_item(int32_t it, int srow, float (&v)[KPL], float &w, bool fresh = true) const {
+        if constexpr (STRIPE) {
+            if (srow >= 0) {
+                const int base = srow * (F + 1);
+                const float own = a.stripe_own ? kHotUnit : 0.0f;
+                if (!fresh || !a.stripe_exact) {
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        v[k] = dword_ok(k) ? sn_snap[base + dword_f(k)] + (float)sn_delta[base + dword_f(k)] * own : 0.0f;
+                    w = sn_snap[base + F] + (float)sn_delta[base + F] * own;
+                } else if (a.stripe_exact == 2) {     // experiment: read through the memory-side atomic unit
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        v[k] = dword_ok(k) ? __hip_atomic_fetch_add(a.v_i + (size_t)it * F + dword_f(k), 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+                    w = __hip_atomic_fetch_add(a.w_i + (size_t)it * a.w_stride, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (dword_ok(k)) v[k] += (float)sn_delta[base + dword_f(k)] * own;
+                    w += (float)sn_delta[base + F] * own;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k) v[k] = dword_ok(k) ? load_f32<true>(a.v_i + (size_t)it * F + dword_f(k)) : 0.0f;
+                    w = load_f32<true>(a.w_i + (size_t)it * a.w_stride);
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (dword_ok(k)) v[k] += (float)sn_delta[base + dword_f(k)] * own;
+                    w += (float)sn_delta[base + F] * own;
+                }
+                return;
+            }
+        }
+        load_row<FRESH>(a.v_i + (size_t)it * F, v);
+        w = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
+    }
+    // raw draw -> candidate item (and its stripe row)
+    __device__ __forceinline__ int32_t draw_item(uint32_t raw, int &srow, uint32_t attempt) const {
+        if (STRIPE && sn_rows > 0 && attempt < RFM_STRIPE_ATTEMPTS) {
+            srow = (int)rfm_draw_to_item(raw, (uint32_t)sn_rows);
+            return sn_item[srow];
+        } else {
+            srow = -1;
+            return (int32_t)rfm_draw_to_item(raw, (uint32_t)a.n_items);
+        }
     }
 
     __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_, TabPtr v_uf, TabPtr v_if, TabPtr w_if)
@@ -395,9 +528,9 @@ struct RowStep {
     //   w_i[it] + sum_q x_if[it,q] w_if[q] + sum_f [ (vu_f + A_f) * vi_f + B_f(it) * vu_f ]
     // A = x_uf[u] . v_uf  (user-feature projection), B(it) = x_if[it] . v_if  (item-feature projection)
     __device__ __forceinline__ float utility(const float (&vu)[KPL], const float (&A)[KPL], int32_t it, float (&vi)[KPL],
-                                             float (&B)[KPL], float &wi, int slot = -1, const XV *xit = nullptr) const {
-        load_row<FRESH>(a.v_i + (size_t)it * F, vi);
-        wi = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
+                                             float (&B)[KPL], float &wi, int slot = -1, const XV *xit = nullptr, int srow = -1,
+                                             bool fresh = true) const {
+        fetch_item(it, srow, vi, wi, fresh);
         if constexpr (HOT) {
             if (slot >= 0) {      // the workgroup's own pending updates of a hot row are part of its view of the row
 #pragma unroll
@@ -427,8 +560,9 @@ struct RowStep {
     }
 
     // draw the next unobserved item for the user (rankfm/_rankfm.pyx:250-253)
-    __device__ __forceinline__ int32_t next_negative(int64_t lo, int64_t hi, uint32_t row_key, uint32_t &attempt) const {
+    __device__ __forceinline__ int32_t next_negative(int64_t lo, int64_t hi, uint32_t row_key, uint32_t &attempt, int &srow) const {
         int32_t j = 0;
+        srow = -1;
         if (SERIAL && a.rng == 0 /* RFM_RNG_MT19937 */) {
             if (sub == 0) {
                 do { j = (int32_t)(mt_next_global(a.mt_state) % (uint32_t)a.n_items); } while (is_member(a.csr_items, lo, hi, j));
@@ -436,18 +570,35 @@ struct RowStep {
             j = __shfl(j, (threadIdx.x & 63) - sub);
         } else {
             for (;;) {
-                j = (int32_t)rfm_draw_to_item(rfm_draw(row_key, attempt), (uint32_t)a.n_items);
+                j = draw_item(rfm_draw(row_key, attempt), srow, attempt);
                 ++attempt;
-                if (!is_member_group<G>(a.csr_items, lo, hi, j, sub)) break;
+                if (!member(lo, hi, j)) break;
                 if (attempt >= kMaxAttempts) { if (sub == 0) atomicOr(a.error_flags, 1u); break; }
             }
         }
         return j;
     }
 
+    // the positive item's row, bias and step scale fetched ahead of the row's turn (segments kernel, STRIPE): rows of a segment
+    // depend on each other only through v_u, which lives in registers, so the next row's gathers overlap the current row
+    struct PosRow { float v[KPL]; float w, scale; };
+    __device__ __forceinline__ void prefetch_pos(int32_t it, PosRow &p) const {
+        load_row<FRESH>(a.v_i + (size_t)it * F, p.v);
+        if (a.scale_in_pad) {
+            // lanes 0 / 1 of the group read dwords 0 / 1 of the item's line: bias and step scale in ONE request
+            const float x = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride + (sub & 1));
+            const int base = (threadIdx.x & 63) - sub;
+            p.w = __shfl(x, base);
+            p.scale = __shfl(x, base + 1);
+        } else {
+            p.w = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
+            p.scale = a.pos_scale ? a.pos_scale[it] : 1.0f;
+        }
+    }
+
     // `vu` holds v_u[u] on entry; with VU_REGS it holds the updated row on exit
     __device__ __forceinline__ void operator()(uint32_t row_key, int32_t u, int32_t i, float sw, int64_t lo, int64_t hi,
-                                               float (&vu)[KPL], double &ll_acc, unsigned &draw_acc) const {
+                                               float (&vu)[KPL], double &ll_acc, unsigned &draw_acc, const PosRow *pre = nullptr) const {
         uint32_t attempt = 0;
         float A[KPL];
         XV xu, xi, xj, xc;
@@ -461,7 +612,7 @@ struct RowStep {
         float pos_scale_i = 1.0f;
         if constexpr (!SERIAL) {
             if (a.pos_scale) {
-                pos_scale_i = a.pos_scale[i];
+                pos_scale_i = pre ? pre->scale : a.pos_scale[i];
                 if constexpr (HOT) {
                     if (pos_scale_i >= 2.0f) {
                         slot = (int)(pos_scale_i * 0.5f) - 1;
@@ -474,6 +625,7 @@ struct RowStep {
         float vj[KPL], Bj[KPL], wj = 0.0f;
         float min_pu = 1e6f;
         int32_t j = -1;
+        int jrow = -1;                // stripe row of the chosen negative (STRIPE)
         int sampled = 0;
         float ut_ui = 0.0f;
         int s = 1;
@@ -486,7 +638,8 @@ struct RowStep {
         // (the reference's ut_ui - ut_uj, :239 and :256-257, regrouped; Bi then holds B(i) - B(j) and Bj zero)
         constexpr bool BPRF = FEAT && LDSF && !WARPB;
         if constexpr (BPRF) {
-            j = next_negative(lo, hi, row_key, attempt);
+            int srow_unused;
+            j = next_negative(lo, hi, row_key, attempt, srow_unused);
             sampled = 1;
             load_row<FRESH>(a.v_i + (size_t)i * F, vi);
             load_row<FRESH>(a.v_i + (size_t)j * F, vj);
@@ -521,19 +674,46 @@ struct RowStep {
             for (int k = 0; k < KPL; ++k) part += (vu[k] + A[k]) * (vi[k] - vj[k]) + Bi[k] * vu[k];
             min_pu = (wi - wj) + scalar + group_sum<G>(part);
         } else {
+        if (STRIPE && pre) {
+            // (STRIPE has no features: the utility is bias + dot product, on the prefetched row)
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) vi[k] = pre->v[k];
+            wi = pre->w;
+            if constexpr (HOT) {
+                if (slot >= 0) {
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (dword_ok(k)) vi[k] += (float)hot_acc[slot * F + dword_f(k)] * kHotUnit;
+                    wi += (float)hot_accw[slot] * kHotUnit;
+                }
+            }
+            if (a.stripe_mean && sn_rows > 0) {
+                const float c = kHotUnit * sn_inv_rows;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k)
+                    if (dword_ok(k)) vi[k] += (float)sn_sum[dword_f(k)] * c;
+                wi += (float)sn_sum[F] * c;
+            }
+            float part = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) part += vu[k] * vi[k];
+            ut_ui = wi + group_sum<G>(part);
+        } else
         ut_ui = utility(vu, A, i, vi, Bi, wi, slot, &xi);    // :239
 
         // WARP sampling loop (:244-264); BPR is max_samples == 1
         // first draw (all of BPR): one candidate at a time
         for (; s <= ((BATCH_WARP || (!SERIAL && !FEAT && !WARPB)) ? 1 : a.max_samples); ++s) {
-            const int32_t cand = next_negative(lo, hi, row_key, attempt);
+            int crow;
+            const int32_t cand = next_negative(lo, hi, row_key, attempt, crow);
             float vc[KPL], Bc[KPL], wc;
             if constexpr (FEAT) { if (a.has_if) xload(a.x_if + (size_t)cand * a.n_if, a.n_if, xc); }
-            const float pu = ut_ui - utility(vu, A, cand, vc, Bc, wc, -1, &xc);   // :256-257
+            // (stripes: BPR steps its one candidate -> exact view; WARP screens candidates on the snapshot)
+            const float pu = ut_ui - utility(vu, A, cand, vc, Bc, wc, -1, &xc, crow, !(STRIPE && WARPB));   // :256-257
             sampled = s;
             if (pu < min_pu || j < 0) {                                   // :259-261 (j < 0: keep a valid index under NaN)
                 if (pu < min_pu) min_pu = pu;
-                j = cand; wj = wc;
+                j = cand; wj = wc; jrow = crow;
                 if constexpr (FEAT) xj = xc;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) { vj[k] = vc[k]; if constexpr (FEAT) Bj[k] = Bc[k]; }
@@ -548,11 +728,12 @@ struct RowStep {
             s = 2;
             while (!done && s <= a.max_samples) {
                 int32_t c[4];
+                int crow[4];
                 bool mem[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) c[q] = (int32_t)rfm_draw_to_item(rfm_draw(row_key, attempt + q), (uint32_t)a.n_items);
+                for (int q = 0; q < 4; ++q) c[q] = draw_item(rfm_draw(row_key, attempt + q), crow[q], attempt + q);
                 attempt += 4;
-                members4_group<G>(a.csr_items, lo, hi, c, mem, sub);
+                members4(lo, hi, c, mem);
                 // rows are fetched NB at a time: four at KPL <= 6; two at KPL >= 8, where four rows of registers spill and two
                 // rows are as many requests in flight as four rows at KPL = 4
                 constexpr int NB = KPL >= 8 ? 2 : 4;
@@ -564,10 +745,7 @@ struct RowStep {
                     for (int q = 0; q < NB; ++q) {
                         part[q] = 0.0f;
                         wc[q] = 0.0f;
-                        if (!mem[q0 + q]) {
-                            load_row<FRESH>(a.v_i + (size_t)c[q0 + q] * F, vc[q]);
-                            wc[q] = load_f32<FRESH>(a.w_i + (size_t)c[q0 + q] * a.w_stride);
-                        }
+                        if (!mem[q0 + q]) fetch_item(c[q0 + q], crow[q0 + q], vc[q], wc[q], false);
                     }
 #pragma unroll
                     for (int q = 0; q < NB; ++q)
@@ -584,7 +762,7 @@ struct RowStep {
                         sampled = s;
                         ++s;
                         if (pu < min_pu) {
-                            min_pu = pu; j = c[q0 + q]; wj = wc[q];
+                            min_pu = pu; j = c[q0 + q]; wj = wc[q]; jrow = crow[q0 + q];
 #pragma unroll
                             for (int k = 0; k < KPL; ++k) vj[k] = vc[q][k];
                         }
@@ -592,6 +770,16 @@ struct RowStep {
                     }
                 }
                 if (attempt >= kMaxAttempts) { if (sub == 0) atomicOr(a.error_flags, 1u); break; }
+            }
+        }
+        if constexpr (STRIPE && WARPB) {
+            // the negative that was chosen on the snapshot is stepped on its exact view: row, bias and pairwise utility again
+            if (jrow >= 0 && a.stripe_exact) {
+                fetch_item(j, jrow, vj, wj, true);
+                float part = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) part += vu[k] * vj[k];
+                min_pu = ut_ui - (wj + group_sum<G>(part));
             }
         }
         const float pu = min_pu;                                          // :267-268
@@ -608,7 +796,7 @@ struct RowStep {
         }
         const bool plain_items = !SERIAL && a.update_mode == 2, plain_user = !SERIAL && (a.update_mode == 1 || a.update_mode == 2);
         // experiment (update_mode 3): drop the positive item's atomics when the item is hot -- measures what they cost
-        const bool skip_pos = !SERIAL && a.update_mode == 3 && pos_scale_i < 1.0f;
+        const bool skip_pos = !SERIAL && ((a.update_mode == 3 && pos_scale_i < 1.0f) || a.update_mode == 4);   // 4: timing experiment
 
         // item biases (:279-280) -- one lane per group
         if (sub == 0) {
@@ -616,7 +804,10 @@ struct RowStep {
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
             if (HOT && slot >= 0) hot_add(hot_accw + slot, dwi);
             else if (!skip_pos) apply_f32<SERIAL>(a.w_i + (size_t)i * a.w_stride, wi, dwi, plain_items);
-            apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj, plain_items);
+            if (STRIPE && jrow >= 0 && !a.stripe_bias_direct) {
+                hot_add(sn_delta + jrow * (F + 1) + F, dwj);
+                if (a.stripe_mean) hot_add(sn_sum + F, dwj);
+            } else apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj, plain_items);
         }
 
         // item-feature weights (:283-286): every q shrinks, lanes split the q range
@@ -646,7 +837,8 @@ struct RowStep {
                 if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u, plain_user);
                 if (HOT && slot >= 0) hot_add(hot_acc + slot * F + f, d_i);
                 else if (!skip_pos) apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i, plain_items);
-                apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
+                if (STRIPE && jrow >= 0) { hot_add(sn_delta + jrow * (F + 1) + f, d_j); if (a.stripe_mean) hot_add(sn_sum + f, d_j); }
+                else apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
             }
         }
         if constexpr (VU_REGS) {
@@ -656,10 +848,8 @@ struct RowStep {
         if constexpr (HOT) {
             if (slot >= 0) {
                 // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it
-                int c = 0;
-                if (sub == 0) c = __hip_atomic_fetch_add(hot_cnt + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
-                c = __shfl(c, (threadIdx.x & 63) - sub);
-                if (c % a.hot_period[slot] == 0) {
+                // (a keyed coin with probability 1 / period instead of a shared counter: no LDS round trip on the row's path)
+                if (rfm_mix32(row_key ^ 0x7A5C3B1DU) % (uint32_t)a.hot_period[slot] == 0u) {
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
@@ -907,8 +1097,16 @@ static __global__ void __launch_bounds__(256) hot_reduce_kernel(const SgdArgs a)
 // larger workgroups mean fewer replicas for the same number of interactions in flight.
 // The HOT instantiation (no features) also uses 1024 threads: the hot-row accumulators are per workgroup, and fewer,
 // larger workgroups combine more touches per publication at the same amount of unpublished work.
-template <int G, int KPL, bool FEAT, bool FRESH, bool HOT = false, bool WARPB = true>
-__global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
+//
+// The STRIPE instantiation (production, no features) also uses 1024 threads, one workgroup per CU, and most of the CU's LDS:
+// the workgroup draws the negatives of a WINDOW of rows (stripe_window per group) from a STRIPE of stripe_rows items
+// (include/rfm_rng.h) whose factor rows and biases it snapshots into LDS when the window starts.  Candidate rows are then LDS
+// reads (WARP examines ~20 per update), the chosen negative's update is an LDS add into a fixed-point pending sum, and when
+// the window ends every stripe row is published with ONE set of atomics however many updates it received -- with
+// 64 groups x 32 rows on 256 stripe rows about eight.  That takes the negative item's 4 + 1 memory-side atomic requests per
+// update (of ~10, the kernel's bound: DESIGN.md section 7) down to ~0.6, and the negative's row reads from 5 to ~0.6.
+template <int G, int KPL, bool FEAT, bool FRESH, bool HOT = false, bool WARPB = true, bool STRIPE = false>
+__global__ void __launch_bounds__((FEAT || HOT || STRIPE) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -923,7 +1121,7 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         __syncthreads();
     }
     lds_float *lds = (lds_float *)lds_tables;
-    typedef RowStep<G, KPL, false, FEAT, true, FRESH, FEAT, HOT, WARPB> Step;
+    typedef RowStep<G, KPL, false, FEAT, true, FRESH, FEAT, HOT, WARPB, STRIPE> Step;
     Step step = [&]() {
         if constexpr (FEAT) return Step(a, sub, lds, lds + a.n_uf * F, lds + (a.n_uf + a.n_if) * F);
         else return Step(a, sub, a.v_uf, a.v_if, a.w_if);
@@ -955,10 +1153,71 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
         step.hot_acc = (lds_int *)lds;
         step.hot_accw = (lds_int *)(lds + a.n_hot * F);
         step.hot_cnt = (lds_int *)(lds + a.n_hot * (F + 1));
+    }
+    if constexpr (HOT || STRIPE) {
         // steps scale with learning rate x sample weight: unit 2^-24 at the defaults (eta 0.1, weights <= 1)
         const float range = fmaxf(1.0f, __uint_as_float(*a.sw_max_bits) * a.eta * 10.0f);
         step.kHotScale = 16777216.0f / range;
         step.kHotUnit = range / 16777216.0f;
+    }
+    // negative stripe: [R] items | [R, F+1] snapshot | [R, F+1] pending, behind the hot-row accumulators
+    const int R = STRIPE ? a.stripe_rows : 0, FS = F + 1;
+    if constexpr (STRIPE) {
+        lds_float *base = lds + (HOT ? a.n_hot * (F + 2) : 0);
+        step.sn_item = (lds_int *)base;
+        step.sn_snap = base + R;
+        step.sn_delta = (lds_int *)(base + R + R * FS);
+        step.sn_sum = (lds_int *)(base + R + 2 * R * FS);
+        // mean pending sum of a random ITEM = mean over this stripe's rows x the chance that the item is in a stripe at all
+        step.sn_inv_rows = a.stripe_cover / (float)R;
+        step.sn_rows = R;
+    }
+    // window turn-over: every stripe row is published (one atomic per touched 64-byte segment, whatever the number of
+    // updates it received) and, when work remains, replaced by the same row of the next stripe.  Row `slot` is handled by
+    // one 16-lane group; loads bypass L1 (other workgroups' atomics must be seen).
+    auto stripe_turn = [&](bool flush, bool load, uint32_t window) {
+        const int gw = threadIdx.x / G, ngw = blockDim.x / G;
+        const uint32_t start = load ? rfm_stripe_start(a.epoch_key, a.launch_index, blockIdx.x, gridDim.x, window, (uint32_t)R, (uint32_t)a.n_items) : 0u;
+        if (load) for (int k = threadIdx.x; k < FS; k += blockDim.x) step.sn_sum[k] = 0;
+        for (int slot = gw; slot < R; slot += ngw) {
+            const int base = slot * FS;
+            if (flush) {
+                const int32_t it = step.sn_item[slot];
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) {
+                    const int f = sub + G * k;
+                    if (f < F) {
+                        const int d = step.sn_delta[base + f];
+                        if (d != 0) atomic_add_f32(a.v_i + (size_t)it * F + f, (float)d * step.kHotUnit);
+                    }
+                }
+                if (sub == 0 && !a.stripe_bias_direct) {
+                    const int d = step.sn_delta[base + F];
+                    if (d != 0) atomic_add_f32(a.w_i + (size_t)it * a.w_stride, (float)d * step.kHotUnit);
+                }
+            }
+            if (load) {
+                const int32_t it = (int32_t)rfm_stripe_item(a.epoch_key, start, (uint32_t)slot, (uint32_t)a.n_items, a.item_bits);
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) {
+                    const int f = sub + G * k;
+                    if (f < F) {
+                        if (WARPB || !a.stripe_exact) step.sn_snap[base + f] = load_f32<true>(a.v_i + (size_t)it * F + f);   // screening view
+                        step.sn_delta[base + f] = 0;
+                    }
+                }
+                if (sub == 0) {
+                    if (WARPB || !a.stripe_exact) step.sn_snap[base + F] = load_f32<true>(a.w_i + (size_t)it * a.w_stride);
+                    step.sn_delta[base + F] = 0;
+                    step.sn_item[slot] = it;
+                }
+            }
+        }
+    };
+    uint32_t window = 0;
+    if constexpr (STRIPE) {
+        if (R > 0) stripe_turn(false, true, 0);
+        __syncthreads();
     }
 
     double ll_acc = 0.0;
@@ -973,9 +1232,43 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
     float vu[KPL], vu0[KPL];
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
+    constexpr int SEGR = (kSegmentRows + G - 1) / G;     // rows of a segment per lane
+    int32_t seg_item[SEGR], seg_pos[SEGR];
+    float seg_sw[SEGR];
+    typename Step::PosRow cur_pos, next_pos;
+    const int lane_base = lane - sub;
+    // row t of the segment: register t / G of lane t % G (the register index is selected, not indexed: registers stay registers)
+    auto seg_get = [&](const int32_t (&r)[SEGR], int tt) {
+        int32_t x = r[0];
+#pragma unroll
+        for (int k = 1; k < SEGR; ++k) x = (tt / G == k) ? r[k] : x;
+        return __shfl(x, lane_base + tt % G);
+    };
+    auto seg_getf = [&](const float (&r)[SEGR], int tt) {
+        float x = r[0];
+#pragma unroll
+        for (int k = 1; k < SEGR; ++k) x = (tt / G == k) ? r[k] : x;
+        return __shfl(x, lane_base + tt % G);
+    };
 
     for (int iter = 0;; ++iter) {
-        if constexpr (!FEAT) { if (!__any(active)) break; }
+        if constexpr (!FEAT && !STRIPE) { if (!__any(active)) break; }
+        if constexpr (STRIPE) {
+            // (stripe_rows = 0: the pipelined row loop alone -- draws over the whole catalogue, atomics per negative)
+            if (R == 0) { if (!__any(active)) break; }
+            // window boundary (workgroup-uniform): all of the window's LDS adds are done behind the barrier
+            else if (iter > 0 && iter % a.stripe_window == 0) {
+                const bool more = __syncthreads_or(active) != 0;
+                // (one group alone is a sequential program: the previous row's atomics must have been performed before this
+                // row reads the same addresses again)
+                if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                stripe_turn(true, false, 0);
+                if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                stripe_turn(false, more, ++window);
+                __syncthreads();
+                if (!more) break;
+            }
+        }
         if constexpr (HOT) {
             // bin sweeping duty (see SgdArgs::hot_bins_v): the wavefronts of a workgroup take turns, one turn per row; a turn
             // sweeps the workgroup's lines (at most four, else the host chose hot_direct)
@@ -998,12 +1291,37 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
             }
             t = 0;
             have = true;
+            if constexpr (STRIPE) {
+                step.load_ulist(lo, hi);
+                // the segment's rows in visiting order, held across the lanes (row t in lane t % G, register t / G): item,
+                // sample weight and CSR position come out of registers for the rest of the segment
+#pragma unroll
+                for (int k = 0; k < SEGR; ++k) {
+                    const int tt = sub + G * k;
+                    seg_pos[k] = tt < len ? begin + (int32_t)rfm_perm((uint32_t)tt, (uint32_t)len, (uint32_t)len_bits, seg_key) : begin;
+                    seg_item[k] = a.csr_items[seg_pos[k]];
+                    seg_sw[k] = a.sw_csr[seg_pos[k]];
+                }
+                step.prefetch_pos(seg_get(seg_item, 0), next_pos);
+            }
         }
         if (active) {
-            const int32_t pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);
-            const int32_t i = a.csr_items[pos];
-            const float sw = a.sw_csr[pos];
-            step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+            int32_t pos, i;
+            float sw;
+            if constexpr (STRIPE) {
+                pos = seg_get(seg_pos, t); i = seg_get(seg_item, t); sw = seg_getf(seg_sw, t);
+                cur_pos = next_pos;
+                // (one group alone is a sequential program: a repeated (user, item) row must see the previous row's update of
+                // the same item, so nothing is fetched ahead there)
+                if (a.single_group) step.prefetch_pos(i, cur_pos);
+                else if (t + 1 < len) step.prefetch_pos(seg_get(seg_item, t + 1), next_pos);     // overlaps this row
+                step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc, &cur_pos);
+            } else {
+                pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);
+                i = a.csr_items[pos];
+                sw = a.sw_csr[pos];
+                step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+            }
             if (++t == len) {
                 // one write-back per segment; other segments of a heavy user may be in flight, so add the delta
 #pragma unroll
@@ -1058,7 +1376,8 @@ __global__ void __launch_bounds__((FEAT || HOT) ? 1024 : 256) sgd_segments_kerne
 }
 
 // host-side launcher table (rfm_sgd_inst_*.hip): [0..3] rows kernel {hogwild, hogwild+feat, serial, serial+feat},
-// [4..7] segments kernel {plain, feat, fresh, fresh+feat}, [8..9] segments kernel with hot-row accumulators {plain, fresh}
+// [4..7] segments kernel {plain, feat, fresh, fresh+feat}, [8..9] segments kernel with hot-row accumulators {plain, fresh},
+// [10..13] segments kernel with negative stripes {plain, fresh, hot, hot+fresh}
 typedef void (*sgd_launch_fn)(const SgdArgs &, int grid, hipStream_t);
 
 }  // namespace rfm

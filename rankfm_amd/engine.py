@@ -114,6 +114,8 @@ class DeviceSession:
             stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = _hip.lib().rfm_fit_device(C.byref(cfg), C.byref(buf), C.c_void_p(stream), C.byref(rep))
         self._plan_token = int(rep.plan_token) if (rc == _hip.OK and perms is None) else 0
+        self._geometry = dict(rep.geometry(), single_group=bool(self.debug_flags & 1), seed=self.seed,
+                              epoch_part=part)
         out = dict(status=rc, log_likelihood=ll, reg_penalty=pen, sgd_kernel_ms=ms, n_draws=draws,
                    epochs_done=rep.epochs_done, launches_per_epoch=rep.launches_per_epoch,
                    waves_per_launch=rep.waves_per_launch)

@@ -66,6 +66,12 @@ def segments(csr_offsets):
 
 def epoch_positions(csr_offsets, seed, epoch):
     """CSR positions in the order the segments kernel visits them in `epoch` (single-group / sequential order)"""
+    return _visit(csr_offsets, seed, epoch)[0]
+
+
+def _visit(csr_offsets, seed, epoch):
+    """per visited row, in the sequential (segment order, then within-segment) enumeration of `epoch_positions`:
+    (CSR position, segment-order position sp of its segment, index t inside the segment), and the segment lengths by sp"""
     users, begin, length = segments(csr_offsets)
     S = len(users)
     ek = epoch_key(seed, epoch)
@@ -76,10 +82,58 @@ def epoch_positions(csr_offsets, seed, epoch):
     lr = np.repeat(l, l)
     bits = np.array([perm_bits(int(v)) for v in range(SEGMENT_ROWS + 1)], dtype=np.uint64)[lr]
     within = perm(t, lr, bits, np.repeat(seg_key, l))
-    return np.repeat(b, l) + within
+    return np.repeat(b, l) + within, np.repeat(np.arange(S, dtype=np.int64), l), t, l, ek
 
 
-def oracle_stripes(csr_offsets, seed, epoch, geometry):
+def row_stripes(csr_offsets, seed, epoch, geometry):
+    """int32 [N]: the first position of the negative stripe (include/rfm_rng.h) every CSR position draws from in `epoch`, for the launch geometry the
+    engine reported (DeviceSession.geometry() / the `geometry` entry of `_fit`'s report).  Restates the schedule of
+    sgd_segments_kernel<STRIPE>: row group g of a launch walks the segments at order positions p0 + g, p0 + g + n_groups, ...;
+    its k-th row of the launch lies in window k // stripe_window of its workgroup g // groups_per_workgroup; the stripe of
+    (workgroup, window) starts at rfm_stripe_start."""
+    R, RW = geometry["stripe_rows"], geometry["stripe_window"]
+    n_items = int(geometry["n_items"])
+    pos, sp, t, seg_len, ek = _visit(csr_offsets, seed, epoch)
+    S = len(seg_len)
+    n_groups = 1 if geometry["single_group"] else int(geometry["working_groups"])
+    gpw, grid = int(geometry["groups_per_workgroup"]), (1 if geometry["single_group"] else int(geometry["workgroups"]))
+    upl = int(geometry["units_per_launch"])
+    u_begin, u_end = 0, S
+    if geometry.get("epoch_part"):
+        k, n = geometry["epoch_part"]
+        u_begin, u_end = S * k // n, S * (k + 1) // n
+    start_iter = np.zeros(S, dtype=np.int64)       # rows its group has done in the launch before the segment
+    launch_of = np.full(S, -1, dtype=np.int64)
+    group_of = np.zeros(S, dtype=np.int64)
+    for launch, p0 in enumerate(range(u_begin, u_end, upl)):
+        p1 = min(p0 + upl, u_end)
+        k = np.arange(p1 - p0, dtype=np.int64)
+        stride = 1 if geometry["single_group"] else n_groups
+        rounds = (len(k) + stride - 1) // stride
+        m = np.zeros(rounds * stride, dtype=np.int64)
+        m[:len(k)] = seg_len[p0:p1]
+        m = m.reshape(rounds, stride)
+        before = (np.cumsum(m, axis=0) - m).reshape(-1)[:len(k)]
+        if geometry["single_group"]:               # one group walks the launch's segments one after the other
+            before = np.cumsum(seg_len[p0:p1]) - seg_len[p0:p1]
+        start_iter[p0:p1] = before
+        launch_of[p0:p1] = launch
+        group_of[p0:p1] = 0 if geometry["single_group"] else k % n_groups
+    it = start_iter[sp] + t
+    window = it // RW
+    wg = group_of[sp] // gpw
+    salt = mix32((np.uint64(ek) ^ ((np.uint64(0x68E31DA4) + launch_of[sp].astype(np.uint64)) & _M32)) & _M32)
+    stripe = ((window * grid + wg).astype(np.uint64) * np.uint64(R) + salt) % np.uint64(n_items)       # rfm_stripe_start
+    out = np.zeros(len(pos), dtype=np.int32)
+    out[pos] = stripe.astype(np.int32)
+    return out
+
+
+def oracle_stripes(csr_offsets, seed, epochs, geometry, n_items):
     """extra keyword arguments for oracle.fit that make the sequential oracle draw its negatives exactly like the launch
-    described by `geometry` (DeviceSession.geometry()); {} when the engine draws over the whole catalogue"""
-    return {}
+    described by `geometry` (DeviceSession.geometry()); {} when the engine draws over the whole catalogue.  `epochs` is an
+    iterable of (absolute) epoch indexes."""
+    if not geometry or not geometry.get("stripe_rows"):
+        return {}
+    g = dict(geometry, n_items=n_items)
+    return dict(row_stripe=np.stack([row_stripes(csr_offsets, seed, e, g) for e in epochs]), stripe_rows=int(g["stripe_rows"]))

@@ -20,7 +20,8 @@ def _run(pairs, csr, sw, F, max_samples, epochs, seed, engine_kw, oracle, sigma=
     rep = {}
     _fit(pairs, sw, csr, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"], 0.01, 0.1, 0.1, schedule, 0.25,
          max_samples, epochs, False, engine=EngineOptions(seed=seed, **engine_kw), report=rep)
-    o, out = _oracle_in_engine_order(oracle, (pairs, csr, sw, x_uf, x_if, None), w0, max_samples, epochs, seed, schedule=schedule)
+    o, out = _oracle_in_engine_order(oracle, (pairs, csr, sw, x_uf, x_if, None), w0, max_samples, epochs, seed, schedule=schedule,
+                                     geometry=rep["geometry"])
     return g, rep, o, out
 
 
@@ -133,9 +134,11 @@ def test_epoch_parts_compose_to_the_whole_epoch():
     sw = np.ones(len(pairs), np.float32)
     w0 = synthetic.init_weights(200, 150, 16, seed=2)
     z_u, z_i = np.zeros((200, 1), np.float32), np.zeros((150, 1), np.float32)
-    whole = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
+    # (debug_flags 1 | 8: one group, draws over the whole catalogue -- the negative-stripe schedule restarts with every launch,
+    # so with stripes the slices draw other, equally valid negatives than the whole epoch does: checked below)
+    whole = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=9)
     r0 = whole.run(epochs=1)
-    sliced = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
+    sliced = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=9)
     ll, draws = 0.0, 0
     for k in range(5):
         r = sliced.run(epochs=1, part=(k, 5))
@@ -147,6 +150,10 @@ def test_epoch_parts_compose_to_the_whole_epoch():
     assert draws == r0["n_draws"][0] == len(pairs) and ll == pytest.approx(r0["log_likelihood"][0], rel=1e-9)
     with pytest.raises(ValueError):
         sliced.run(epochs=1, part=(5, 5))
+    striped = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
+    rs = [striped.run(epochs=1, part=(k, 5)) for k in range(5)]
+    assert sum(int(r["n_draws"][0]) for r in rs) == len(pairs)
+    assert sum(float(r["log_likelihood"][0]) for r in rs) == pytest.approx(r0["log_likelihood"][0], rel=0.02)
 
 
 def test_duplicate_heavy_user_with_more_rows_than_items_trains(oracle):

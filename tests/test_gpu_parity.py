@@ -81,9 +81,10 @@ def _problem(U, I, N, F, seed, n_uf=0, n_if=0, sigma=0.1, random_sw=False):
     return pairs, csr, sw, x_uf, x_if, w
 
 
-def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1, schedule="constant"):
+def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1, schedule="constant", geometry=None):
     """The sequential CPU oracle on exactly the order and draws of the Hogwild segments kernel: interactions re-ordered to
-    CSR positions (the kernel keys its counter RNG by CSR position), visiting order from rankfm_amd.order."""
+    CSR positions (the kernel keys its counter RNG by CSR position), visiting order and -- given the launch `geometry` the
+    engine reported -- the negative stripe of every row from rankfm_amd.order."""
     from rankfm_amd import order
     pairs, csr, sw, x_uf, x_if, _ = prob
     by_csr = np.lexsort((pairs[:, 1], pairs[:, 0]))
@@ -94,7 +95,8 @@ def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1,
     o = {k: v.copy() for k, v in w0.items()}
     out = oracle.fit(pairs_csr, sw_csr, csr.offsets, csr.items, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"],
                      o["v_if"], 0.01, 0.1, lr, schedule, 0.25, max_samples, epochs, perms=perms, rng_mode=oracle.RNG_COUNTER,
-                     seed=seed, membership="binary", want_negatives=len(pairs) <= 1_000_000)
+                     seed=seed, membership="binary", want_negatives=len(pairs) <= 1_000_000,
+                     **order.oracle_stripes(csr.offsets, seed, range(epochs), geometry, len(w0["w_i"])))
     return o, out
 
 
@@ -107,7 +109,7 @@ def _both(oracle, prob, max_samples, epochs, seed=5, lr=0.1, engine_kw=None):
     _fit(pairs, sw, csr, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"],
          0.01, 0.1, lr, "constant", 0.25, max_samples, epochs, False,
          engine=EngineOptions(mode="hogwild", seed=seed, **(engine_kw or {})), report=rep)
-    o, out = _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr)
+    o, out = _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr, geometry=rep["geometry"])
     return g, rep, o, out
 
 
@@ -240,7 +242,7 @@ def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
     sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=1, seed=1492)
     rep = sess.run(epochs=2)
     g = sess.weights_to_host()
-    o, out = _oracle_in_engine_order(oracle, (pairs, csr, sw, x_uf, x_if, None), w, 1, 2, 1492)
+    o, out = _oracle_in_engine_order(oracle, (pairs, csr, sw, x_uf, x_if, None), w, 1, 2, 1492, geometry=sess.geometry())
     # log-likelihood: 1.8 % in the first epoch (measured +1.2 %: the 64 hottest items are trained through per-workgroup LDS
     # accumulators and damped accordingly, which costs them a little progress early on), 1.2 % in the second (measured +0.8 %);
     # norms measured +0.03 % / +0.12 % / +0.7 % (v_u, v_i, w_i)

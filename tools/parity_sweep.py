@@ -29,6 +29,8 @@ ap.add_argument("--rows-per-launch", default="0")
 ap.add_argument("--sigma", type=float, default=0.1)
 ap.add_argument("--no-oracle", action="store_true")
 ap.add_argument("--debug-flags", default="0")
+ap.add_argument("--lr", type=float, default=0.1)
+ap.add_argument("--env", default="", help="variants of engine environment knobs: 'A=1,B=2;A=3' runs two variants")
 a = ap.parse_args()
 U, I, N, F = a.users, a.items, a.rows, a.factors
 pairs, csr = synthetic.make_interactions(U, I, N, seed=0, zipf_s=a.zipf)
@@ -45,22 +47,29 @@ if not a.no_oracle:
     o = {k: v.copy() for k, v in w.items()}
     t0 = time.time()
     out = orc.fit(pairs_csr, sw, csr.offsets, csr.items, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"],
-                  0.01, 0.1, 0.1, "constant", 0.25, a.max_samples, a.epochs, perms=perms, rng_mode=orc.RNG_COUNTER, seed=1492,
+                  0.01, 0.1, a.lr, "constant", 0.25, a.max_samples, a.epochs, perms=perms, rng_mode=orc.RNG_COUNTER, seed=1492,
                   membership="binary")
     print("oracle %.1fs ll/N %s  " % (time.time() - t0, out["ll"] / N) + " ".join("|%s| %.3f" % (k, np.linalg.norm(o[k])) for k in NAMES), flush=True)
-for wg in [int(x) for x in a.workgroups.split(",")]:
+for envs in a.env.split(";"):
+  for kv in [x for x in envs.split(",") if x]:
+      if kv.split("=")[1] == "":
+          os.environ.pop(kv.split("=")[0], None)
+      else:
+          os.environ[kv.split("=")[0]] = kv.split("=")[1]
+  print("env", envs, flush=True)
+  for wg in [int(x) for x in a.workgroups.split(",")]:
     for rpl in [int(x) for x in a.rows_per_launch.split(",")]:
-        for m, fl in [(float(x), int(y)) for x in a.dampings.split(",") for y in a.debug_flags.split(",")]:
-            sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=a.max_samples, seed=1492,
-                                 hogwild_damping=m, n_workgroups=wg, rows_per_launch=rpl, debug_flags=fl)
-            rep = sess.run(epochs=a.epochs, raise_on_error=False)
-            g = sess.weights_to_host()
-            line = "flags=%d " % fl + "wg=%4d rpl=%8d M=%6.1f st=%d launches=%d ms %s ll/N %s" % (wg, rpl, m, rep["status"], rep["launches_per_epoch"],
-                                                                         np.round(rep["sgd_kernel_ms"], 2), np.round(rep["log_likelihood"] / N, 4))
-            if o is not None:
-                line += "  ll-ratio %s  norm-ratio " % np.round(rep["log_likelihood"] / out["ll"], 4)
-                line += " ".join("%s %.4f" % (k, np.linalg.norm(g[k]) / max(np.linalg.norm(o[k]), 1e-30)) for k in NAMES)
-                line += "  corr " + " ".join("%.4f" % np.corrcoef(g[k].ravel(), o[k].ravel())[0, 1] for k in NAMES)
-            else:
-                line += "  norms " + " ".join("%s %.4g" % (k, np.linalg.norm(g[k])) for k in NAMES)
-            print(line, flush=True)
+          for m, fl in [(float(x), int(y)) for x in a.dampings.split(",") for y in a.debug_flags.split(",")]:
+              sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=a.max_samples, seed=1492, learning_rate=a.lr,
+                                   hogwild_damping=m, n_workgroups=wg, rows_per_launch=rpl, debug_flags=fl)
+              rep = sess.run(epochs=a.epochs, raise_on_error=False)
+              g = sess.weights_to_host()
+              line = "flags=%d " % fl + "wg=%4d rpl=%8d M=%6.1f st=%d launches=%d ms %s ll/N %s" % (wg, rpl, m, rep["status"], rep["launches_per_epoch"],
+                                                                           np.round(rep["sgd_kernel_ms"], 2), np.round(rep["log_likelihood"] / N, 4))
+              if o is not None:
+                  line += "  ll-ratio %s  norm-ratio " % np.round(rep["log_likelihood"] / out["ll"], 4)
+                  line += " ".join("%s %.4f" % (k, np.linalg.norm(g[k]) / max(np.linalg.norm(o[k]), 1e-30)) for k in NAMES)
+                  line += "  corr " + " ".join("%.4f" % np.corrcoef(g[k].ravel(), o[k].ravel())[0, 1] for k in NAMES)
+              else:
+                  line += "  norms " + " ".join("%s %.4g" % (k, np.linalg.norm(g[k])) for k in NAMES)
+              print(line, flush=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the profile artifacts of one round on the GPU box (run through gpurun from the repository root):
-#   tools/profile_bench.sh <tag> [bench.py arguments]
+#   tools/profile_bench.sh <tag> [bench.py arguments]      (RFM_PROFILE_PASSES="stats" = kernel statistics only; "stats FETCH_SIZE ..." = a subset)
 # writes gpurun_out/<tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json and <tag>_pmc.json; copy them into profiles/.
 # The counter passes are separate runs with --kernel-trace only (gpurun refuses --pmc together with other trace domains);
 # FETCH_SIZE and WRITE_SIZE each need a pass of their own (together: "exceeds the capabilities of the hardware to collect").
@@ -12,7 +12,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT/$TAG
 cd /tmp && export TMPDIR=/tmp
 cd $R
-if [ "$PASSES" = all ]; then
+if [ "$PASSES" = all ] || echo " $PASSES " | grep -q " stats "; then
 rocprofv3 --kernel-trace --stats -d $OUT/$TAG/stats -o out --output-format csv -- python bench.py --no-cpu-baseline "$@" > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/$TAG/stats.log
 cp $(find $OUT/$TAG/stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 fi

@@ -25,6 +25,7 @@ ap.add_argument("--tags", type=int, default=0)
 ap.add_argument("--schedule", default="constant")
 ap.add_argument("--workgroups", default="0")
 ap.add_argument("--dampings", default="0")
+ap.add_argument("--env", default="", help="variants of engine environment knobs for the GPU sides: 'A=1,B=2;A=' (empty value unsets)")
 a = ap.parse_args()
 
 rows = []
@@ -36,9 +37,15 @@ for seed in range(a.seeds):
         uf = pd.concat([pd.DataFrame({"u": np.arange(a.users)}), pd.DataFrame(d["user_tags"])], axis=1)
         itf = pd.concat([pd.DataFrame({"i": np.arange(a.items)}), pd.DataFrame(d["item_tags"])], axis=1)
     res = {}
-    sides = ["oracle"] + ["gpu:%s:%s" % (w, m) for w in a.workgroups.split(",") for m in a.dampings.split(",")]
+    sides = ["oracle"] + ["gpu:%s:%s:%s" % (w, m, e) for w in a.workgroups.split(",") for m in a.dampings.split(",") for e in a.env.split(";")]
     for side in sides:
         wg, damp = (int(side.split(":")[1]), float(side.split(":")[2])) if side != "oracle" else (0, 0.0)
+        if side != "oracle":
+            for kv in [x for x in side.split(":", 3)[3].split(",") if x]:
+                if kv.split("=")[1] == "":
+                    os.environ.pop(kv.split("=")[0], None)
+                else:
+                    os.environ[kv.split("=")[0]] = kv.split("=")[1]
         m = RankFM(factors=a.factors, loss=a.loss, max_samples=a.max_samples, learning_schedule=a.schedule,
                    engine=EngineOptions(seed=100 + seed, n_workgroups=wg, damping=damp))
         np.random.seed(seed)
