@@ -450,12 +450,13 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // ---- launch geometry.  unit of work = one interaction (rows kernel) or one user segment (segments kernel)
     const int64_t units = use_segments ? n_segments : N;
     const int groups_per_wave = serial ? 1 : 64 / shape->group;
-    // feature instantiation: the largest workgroup (<= 16 wavefronts) whose table replica + staging area fit in LDS
+    // features kernel: 16 wavefronts per workgroup share one LDS copy of the tables (<= 64 KB, checked above)
     int feat_waves = 16;
-    if (getenv("RFM_FEAT_WAVES")) feat_waves = std::max(1, std::min(16, atoi(getenv("RFM_FEAT_WAVES"))));   // (experiment knob)
-    if (use_segments && feat)
-        while (feat_waves > 1 && feat_lds_bytes(cfg->n_user_features, cfg->n_item_features, cfg->n_factors,
-                                                feat_waves * 64 / shape->group) > kLdsBytes) feat_waves /= 2;
+    if (getenv("RFM_FEAT_WAVES")) feat_waves = std::max(2, std::min(16, atoi(getenv("RFM_FEAT_WAVES"))));   // (experiment knob)
+    // (the table trainer also stages one step per row group: 1 + 2F + P + Q floats each; wide tables take smaller workgroups)
+    while (feat_waves > 2 && sizeof(float) * (feat_table_floats(cfg) + (size_t)feat_waves * (64 / shape->group) *
+                                              (1 + 2 * (size_t)cfg->n_factors + cfg->n_user_features + cfg->n_item_features)) > kLdsBytes)
+        feat_waves /= 2;
     const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : ((use_hot || use_stripes) ? 16 : 4));   // see sgd_segments_kernel
     // stripe geometry: as many rows as the LDS left by the hot-row accumulators holds (at most 256: more rows mean longer
     // windows for the same combining), and a window in which a stripe row receives ~8 updates (groups x window / rows)
@@ -499,17 +500,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         if (cfg->n_workgroups > 0) cap = cfg->n_workgroups;
         grid = (int)(need < cap ? need : cap);
         if (grid < 1 || single_group) grid = 1;
-        // feature tables live in per-workgroup LDS replicas that are merged at the end of every launch.  Split the epoch into
-        // up to 16 windows so merges stay frequent, but keep >= 8 segments per row group and window: a group walks a
-        // segment sequentially, so a window with fewer segments than groups is pure latency (measured: 16 windows of 0.8
-        // segments per group ran at 84 M updates/s).
-        if (use_segments && feat && !single_group && cfg->rows_per_launch <= 0) {
-            const int64_t groups = (int64_t)grid * groups_per_block;
-            int64_t windows = units / (groups * 8);
-            if (windows > 16) windows = 16;
-            if (getenv("RFM_FEAT_WINDOWS")) windows = std::max(1, atoi(getenv("RFM_FEAT_WINDOWS")));   // (experiment knob)
-            if (windows > 1) units_per_launch = (units + windows - 1) / windows;
-        }
+        // features kernel: workgroup 0 is the table trainer -- one of the resident workgroups, not an extra one (a workgroup that
+        // had to wait for a free CU would run its share after everybody else)
+        if (use_segments && feat && !single_group) grid = (int)std::min<int64_t>((int64_t)grid + 1, std::max<int64_t>(cap, 2));
     }
     const int launches = (int)((units + units_per_launch - 1) / units_per_launch);
     if (use_stripes) {
@@ -643,8 +636,6 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.stripe_cover = stripe_rows > 0 ? std::min(1.0f, (float)grid * (float)stripe_rows / (float)cfg->n_items) : 0.0f;
         a.stripe_mean = getenv("RFM_STRIPE_MEAN") ? atoi(getenv("RFM_STRIPE_MEAN")) : 1;   // (experiment knob)
         a.stripe_exact = getenv("RFM_STRIPE_EXACT") ? atoi(getenv("RFM_STRIPE_EXACT")) : 1;   // (experiment knob)
-        a.feat_snapshot = ws.feat_snapshot;
-        a.feat_merge = 1.0f / (float)grid;
         a.block_threads = waves_per_block * 64;
         // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
         a.eta = cfg->learning_schedule == RFM_SCHEDULE_CONSTANT
@@ -661,11 +652,6 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
                                                 0.5f / ((float)in_flight * a.eta * fmaxf(a.reg_b, 1e-6f)))) : 1.0f;
 
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e], stream));
-        // merge rule of the LDS feature replicas: a replica trains on ~rows_per_window / workgroups interactions; if that is
-        // several times the tables' memory 1 / (2 * beta * eta), take one replica (rotating), else average them
-        const double rows_per_replica = (double)N / (double)launches / (double)(grid > 0 ? grid : 1);
-        bool select_replica = rows_per_replica * (double)a.eta * (double)a.reg_b >= 4.0;
-        if (getenv("RFM_FEAT_MERGE")) select_replica = atoi(getenv("RFM_FEAT_MERGE")) == 0;   // (experiment knob: 0 select, 1 average)
         int window = 0;
         // a caller may ask for one part of the epoch's order only (several delta exchanges per epoch on multi-GPU jobs)
         int64_t u_begin = 0, u_end = units;
@@ -674,16 +660,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             u_end = units * (cfg->epoch_part_index + 1) / cfg->epoch_parts;
         }
         for (int64_t p0 = u_begin; p0 < u_end; p0 += units_per_launch, ++window) {
-            a.feat_select_wg = (use_segments && feat && select_replica) ? (int)((e * launches + window) % grid) : -1;
             a.launch_index = (uint32_t)window;
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
-            if (use_segments && feat) {      // the replicas start from, and are merged against, the tables as of now
-                const size_t nu = (size_t)cfg->n_user_features * cfg->n_factors, ni = (size_t)cfg->n_item_features * cfg->n_factors;
-                RFM_HIP(hipMemcpyAsync(ws.feat_snapshot, b->v_uf, sizeof(float) * nu, hipMemcpyDeviceToDevice, stream));
-                RFM_HIP(hipMemcpyAsync(ws.feat_snapshot + nu, b->v_if, sizeof(float) * ni, hipMemcpyDeviceToDevice, stream));
-                RFM_HIP(hipMemcpyAsync(ws.feat_snapshot + nu + ni, b->w_if, sizeof(float) * cfg->n_item_features, hipMemcpyDeviceToDevice, stream));
-            }
             launch(a, grid, stream);
         }
         if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);

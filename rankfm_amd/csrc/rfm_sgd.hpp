@@ -74,25 +74,7 @@ struct SgdArgs {
     int32_t update_mode;                        // experiments: 0 all atomics, 1 v_u plain RMW, 2 everything plain RMW
     int32_t single_group;                       // debug: only group 0 of wavefront 0 works (sequential Hogwild kernel)
     int64_t max_groups;                         // row groups allowed to work (the concurrency cap can be below one workgroup)
-    // dense feature tables as per-workgroup LDS replicas (segments kernel with features): `feat_snapshot` holds
-    // [v_uf | v_if | w_if] as they were when the launch started; a workgroup loads it, trains on its replica and finally
-    // either adds (replica - snapshot) * feat_merge to the global tables (feat_merge = 1 / workgroups: the replicas'
-    // average) or -- feat_select_wg >= 0 -- that one workgroup stores its replica and the others are dropped.  Selection is
-    // the right merge while the tables forget faster than a window lasts (DESIGN.md "feature tables"): sequential SGD
-    // itself only remembers the last ~1/(2*beta*eta) rows, so any one replica is a fair sample of it, noise level included,
-    // whereas the average of K replicas has 1/sqrt(K) of the reference's noise and visibly smaller tables.
-    //
-    // A replica is NOT updated with LDS atomics: ds_add_f32 retires ~3 clocks per active lane on gfx950 whatever the
-    // addresses (tools/microbench/lds_atomic.hip: 193 clk per 64-lane instruction against 8 clk for a plain read + write),
-    // and with them the feature kernel spent 85 % of its time in the LDS atomic unit.  Instead the workgroup steps in
-    // lock-step: every row group handles one interaction against the replica as it stands, STAGES the row's feature steps
-    // (g, d_outer, the updated v_u and v_i - v_j, x_uf[u], x_if[i] - x_if[j]) in LDS, and after a barrier each table row is
-    // walked by one wavefront that applies the staged steps of all groups in group order with plain reads and writes --
-    // the reference's own update formula, row by row, on values that are stale by at most one workgroup step.
-    const float *__restrict__ feat_snapshot;
-    float feat_merge;
-    int32_t feat_select_wg;
-    int32_t block_threads;                      // workgroup size of the feature instantiation (host: LDS budget)
+    int32_t block_threads;                      // workgroup size of the features kernel
     // hot positive items (segments kernel, HOT instantiation): pos_scale[i] >= 2 encodes slot = int(v / 2) - 1 and
     // scale = v - 2 (slot + 1).  A workgroup accumulates its updates of slot s in LDS and publishes them with one set of
     // atomics every hot_period[s] touches (DESIGN.md "hot rows").
@@ -122,10 +104,6 @@ struct SgdArgs {
 };
 constexpr int kHotBins = 16;
 
-// LDS of the feature instantiation: the table replica + two staging areas of `groups` row groups
-inline size_t feat_lds_bytes(int n_uf, int n_if, int n_factors, int groups) {
-    return sizeof(float) * ((size_t)(n_uf + n_if) * n_factors + n_if + 2 * (size_t)groups * (3 + 2 * (size_t)n_factors + n_uf + n_if));
-}
 constexpr size_t kLdsBytes = 160 * 1024;        // per workgroup on gfx950
 // LDS floats of a negative stripe of R rows: [R] items | [R, F+1] snapshot | [R, F+1] pending sums | [F+1] their column sums
 inline size_t stripe_lds_floats(int rows, int n_factors) { return (size_t)rows * (1 + 2 * ((size_t)n_factors + 1)) + (size_t)n_factors + 1; }
@@ -295,23 +273,27 @@ __device__ __forceinline__ float log_sigmoid(float x) {
 //   VU_REGS  v_u lives in the caller's registers: the step updates them in place and does not touch v_u memory
 //   FRESH    item-row loads bypass L1
 // ---------------------------------------------------------------------------------------------
-//   LDSF     the dense feature tables (v_uf, v_if, w_if) are this workgroup's LDS replica: plain step size, LDS atomics
+//   LDSF     the dense feature tables (v_uf, v_if, w_if) are read from this workgroup's LDS copy (see TMODE)
 //   HOT      updates of hot positive items are accumulated in the workgroup's LDS and published every few touches
 //   WARPB    compile the batched WARP draw loop (max_samples > 1); the BPR instantiation stays at ~76 VGPRs without it
 //   STRIPE   negatives come from the workgroup's LDS stripe: candidate rows are read from, and the negative's update is added
 //            to, LDS (snapshot + fixed-point pending delta); the user's item list is tested from registers when it is short
+//   TMODE    with LDSF: what the step updates (sgd_features_kernel).  0 = the rows only (v_u, v_i, w_i; the tables are a read-only
+//            copy), 1 = the tables only (the table trainer: plain read-modify-write on the master copy, groups of a wavefront one
+//            after the other), 2 = both (one group alone: the reference's sequential step)
 template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false, bool WARPB = true,
-          bool STRIPE = false>
+          bool STRIPE = false, int TMODE = 0>
 struct RowStep {
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
     const int F;
     typedef typename TablePtr<LDSF>::type TabPtr;
-    TabPtr t_v_uf, t_v_if, t_w_if;   // feature tables: global memory, or the workgroup's LDS replica (LDSF)
-    // staging area of the workgroup's feature steps (LDSF): [NG,3] {g, d_outer, active} | [NG,F] updated v_u |
-    // [NG,F] updated v_i - v_j | [NG,P] x_uf[u] | [NG,Q] x_if[i] - x_if[j];  wg_group = this group's row in them
-    lds_float *st_row = nullptr, *st_nvu = nullptr, *st_dij = nullptr, *st_xu = nullptr, *st_dx = nullptr;
-    int wg_group = 0;
+    TabPtr t_v_uf, t_v_if, t_w_if;   // feature tables: global memory, or the workgroup's LDS copy (LDSF)
+    static constexpr bool UPD_ROWS = !(FEAT && LDSF) || TMODE != 1;
+    static constexpr bool UPD_TAB = FEAT && (!LDSF || TMODE == 2);
+    // table trainer (TMODE 1): the step's table update is STAGED here -- [0] g * d_outer | [1, F] updated v_u | [F] updated
+    // v_i - v_j | [P] x_uf[u] | [Q] x_if[i] - x_if[j] -- and applied by sgd_features_kernel, table row by table row
+    lds_float *stage = nullptr;
     // LDS [n_hot, F] pending factor deltas, [n_hot] pending bias deltas, [n_hot] touch counters.  The pending sums are
     // 32-bit FIXED POINT: ds_add_u32 takes ~5 clocks per wave instruction where ds_add_f32 takes ~3 clocks per active
     // lane (tools/microbench/lds_atomic.hip), and every cross-lane shuffle of the workgroup queues behind them in the
@@ -492,24 +474,6 @@ struct RowStep {
         } else {
             for (int q = sub; q < va.n; q += G) fn(q, va.mem[q], vb.mem[q]);
         }
-    }
-
-    // dst[q] = va[q] - vb[q] (vb may be null) for the entries this lane owns
-    __device__ __forceinline__ void xstage(const XV &va, const XV *vb, lds_float *dst) const {
-        if (va.n <= G * MAXR) {
-#pragma unroll
-            for (int k = 0; k < MAXR; ++k)
-                if (sub + G * k < va.n) dst[sub + G * k] = vb ? va.r[k] - vb->r[k] : va.r[k];
-        } else {
-            for (int q = sub; q < va.n; q += G) dst[q] = vb ? va.mem[q] - vb->mem[q] : va.mem[q];
-        }
-    }
-
-    // a group without an interaction in this workgroup step contributes nothing to the batch
-    __device__ __forceinline__ void stage_idle() const {
-        if (sub == 0) st_row[3 * wg_group + 2] = 0.0f;
-        if (a.has_uf) for (int q = sub; q < a.n_uf; q += G) st_xu[wg_group * a.n_uf + q] = 0.0f;
-        if (a.has_if) for (int q = sub; q < a.n_if; q += G) st_dx[wg_group * a.n_if + q] = 0.0f;
     }
 
     // acc[f] = sum_r x[r] * table[r, f]   (feature projection into factor space, this lane's dwords)
@@ -784,7 +748,7 @@ struct RowStep {
         }
         const float pu = min_pu;                                          // :267-268
         const float multiplier = a.multiplier[sampled];                   // :269 (integer division inside the log)
-        if (sub == 0) { ll_acc += (double)log_sigmoid(pu); draw_acc += (unsigned)sampled; }   // :270
+        if (UPD_ROWS && sub == 0) { ll_acc += (double)log_sigmoid(pu); draw_acc += (unsigned)sampled; }   // :270
         const float d_outer = 1.0f / (__expf(pu) + 1.0f);                 // :276
         const float g = sw * multiplier;
         const float eta = a.eta, reg_a = a.reg_a, reg_b = a.reg_b;
@@ -799,7 +763,7 @@ struct RowStep {
         const bool skip_pos = !SERIAL && ((a.update_mode == 3 && pos_scale_i < 1.0f) || a.update_mode == 4);   // 4: timing experiment
 
         // item biases (:279-280) -- one lane per group
-        if (sub == 0) {
+        if (UPD_ROWS && sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
             if (HOT && slot >= 0) hot_add(hot_accw + slot, dwi);
@@ -808,16 +772,6 @@ struct RowStep {
                 hot_add(sn_delta + jrow * (F + 1) + F, dwj);
                 if (a.stripe_mean) hot_add(sn_sum + F, dwj);
             } else apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj, plain_items);
-        }
-
-        // item-feature weights (:283-286): every q shrinks, lanes split the q range
-        if constexpr (FEAT && !LDSF) {
-            if (a.has_if) {
-                xown2(xi, xj, [&](int q, float xa, float xb) {
-                    const float w = t_w_if[q];
-                    apply_f32<SERIAL>(t_w_if + q, w, eta_f * (g * (d_outer * (xa - xb)) - reg_b * w));
-                });
-            }
         }
 
         // factor updates (:289-326), this lane's dwords
@@ -832,7 +786,7 @@ struct RowStep {
             const float d_j = eta * (g * (d_outer * -g_i) - reg_a * vj[k]);    // :310
             nvu[k] = vu[k] + d_u;
             dij[k] = (vi[k] + d_i) - (vj[k] + d_j);
-            if (dword_ok(k)) {
+            if (UPD_ROWS && dword_ok(k)) {
                 const int f = dword_f(k);
                 if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u, plain_user);
                 if (HOT && slot >= 0) hot_add(hot_acc + slot * F + f, d_i);
@@ -841,7 +795,7 @@ struct RowStep {
                 else apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
             }
         }
-        if constexpr (VU_REGS) {
+        if constexpr (VU_REGS && UPD_ROWS) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) vu[k] = nvu[k];
         }
@@ -866,23 +820,41 @@ struct RowStep {
             }
         }
 
-        if constexpr (FEAT && LDSF) {
-            // stage the row's feature steps; the workgroup applies them after its barrier (apply_feature_batch)
-            if (sub == 0) {
-                st_row[3 * wg_group] = g;
-                st_row[3 * wg_group + 1] = d_outer;
-                st_row[3 * wg_group + 2] = 1.0f;
-            }
+        if constexpr (FEAT && LDSF && TMODE == 1) {
+            if (sub == 0) stage[0] = g * d_outer;
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
                 if (!dword_ok(k)) continue;
-                st_nvu[wg_group * F + dword_f(k)] = nvu[k];
-                st_dij[wg_group * F + dword_f(k)] = dij[k];
+                stage[1 + dword_f(k)] = nvu[k];
+                stage[1 + F + dword_f(k)] = dij[k];
             }
-            if (a.has_uf) xstage(xu, nullptr, st_xu + wg_group * a.n_uf);
-            if (a.has_if) xstage(xi, &xj, st_dx + wg_group * a.n_if);
+            lds_float *sx = stage + 1 + 2 * F;
+            if (a.has_uf) {
+                if (a.n_uf <= G * MAXR) {
+#pragma unroll
+                    for (int k = 0; k < MAXR; ++k)
+                        if (sub + G * k < a.n_uf) sx[sub + G * k] = xu.r[k];
+                } else for (int q = sub; q < a.n_uf; q += G) sx[q] = xu.mem[q];
+            }
+            sx += a.n_uf;
+            if (a.has_if) {
+                if (a.n_if <= G * MAXR) {
+#pragma unroll
+                    for (int k = 0; k < MAXR; ++k)
+                        if (sub + G * k < a.n_if) sx[sub + G * k] = xi.r[k] - xj.r[k];
+                } else for (int q = sub; q < a.n_if; q += G) sx[q] = xi.mem[q] - xj.mem[q];
+            }
         }
-        if constexpr (FEAT && !LDSF) {
+        if constexpr (UPD_TAB) {
+          {
+            // item-feature weights (:283-286): every q shrinks, lanes split the q range.  (The reference updates them before the
+            // factor loop; within one interaction the three tables do not read each other, so the order is immaterial.)
+            if (a.has_if) {
+                xown2(xi, xj, [&](int q, float xa, float xb) {
+                    const float w = t_w_if[q];
+                    apply_f32<SERIAL || LDSF>(t_w_if + q, w, eta_f * (g * (d_outer * (xa - xb)) - reg_b * w));
+                });
+            }
             // user-feature factors (:313-318): rows p with x_uf[u,p] != 0, using the UPDATED v_i[i]-v_i[j]
             if (a.has_uf) {
                 xfor(xu, [&](int p, float xp) {
@@ -892,7 +864,7 @@ struct RowStep {
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
                         const float t = trow[dword_f(k)];
-                        apply_f32<SERIAL>(trow + dword_f(k), t, eta_f * (g * (d_outer * (xp * dij[k])) - reg_b * t));
+                        apply_f32<SERIAL || LDSF>(trow + dword_f(k), t, eta_f * (g * (d_outer * (xp * dij[k])) - reg_b * t));
                     }
                 });
             }
@@ -908,92 +880,16 @@ struct RowStep {
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
                         const float t = trow[dword_f(k)];
-                        apply_f32<SERIAL>(trow + dword_f(k), t, eta_f * (g * (d_outer * (dx * nvu[k])) - reg_b * t));
+                        apply_f32<SERIAL || LDSF>(trow + dword_f(k), t, eta_f * (g * (d_outer * (dx * nvu[k])) - reg_b * t));
                     }
                 };
                 if (dxv.n <= G * MAXR) xfor(dxv, body);
                 else for (int q = 0; q < dxv.n; ++q) body(q, xi.mem[q] - xj.mem[q]);
             }
+          }
         }
     }
 };
-
-// The workgroup's staged feature steps applied to its LDS replica (see SgdArgs::feat_snapshot).  For one table (rows r,
-// coefficient x[g,r] = x_uf[u_g,r] or x_if[i_g,r] - x_if[j_g,r], vector vec[g,:] = updated v_i - v_j or updated v_u of
-// group g) the batch of the reference's row updates (rankfm/_rankfm.pyx:313-326)
-//     T[r,:] += eta * (g_g * d_outer_g * x[g,r] * vec[g,:] - reg_b * T[r,:])          for every g with x[g,r] != 0
-// applied in group order is, with keep = 1 - eta * reg_b, n = touches(r) and rank(g,r) = touching groups before g,
-//     T[r,:]  = keep^n * ( T[r,:] + eta * sum_g c[g,r] * vec[g,:] ),   c[g,r] = g_g * d_outer_g * x[g,r] * keep^-(rank(g,r)+1)
-// i.e. a [rows x groups] x [groups x F] product: one 32 x 32 tile per wavefront on the matrix cores
-// (v_mfma_f32_32x32x2_f32 is exact fp32), operands read straight from the staging area.  With one group in flight this is
-// the reference's update to rounding.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void apply_feature_batch(const SgdArgs &a, lds_float *t_v_uf, lds_float *t_v_if, lds_float *t_w_if,
-                                                    const lds_float *st_row, const lds_float *st_nvu, const lds_float *st_dij,
-                                                    const lds_float *st_xu, const lds_float *st_dx, int n_groups) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    const int F = a.n_factors;
-    const float eta_f = a.eta, reg_b = a.reg_b;
-    const float keep = 1.0f - eta_f * reg_b;
-    const float inv1 = 1.0f / keep, inv2 = inv1 * inv1, inv3 = inv2 * inv1, inv4 = inv2 * inv2;
-    // 16 x 16 output tiles (v_mfma_f32_16x16x4_f32, four groups per step): 16 tiles for 32 + 32 rows x 64 factors, one per
-    // wavefront of the 1024-thread workgroup
-    const int f_tiles = (F + 15) / 16;
-    const int uf_tiles = a.has_uf ? ((a.n_uf + 15) / 16) * f_tiles : 0;
-    const int if_tiles = a.has_if ? ((a.n_if + 15) / 16) * f_tiles : 0;
-    // w_if (:283-286) is a third table with one column: coefficient x_if[i] - x_if[j] as for v_if, "vector" 1, but EVERY q
-    // is touched (shrinks) by every row
-    const int w_tiles = a.has_if ? (a.n_if + 15) / 16 : 0;
-    for (int tile = wave; tile < uf_tiles + if_tiles + w_tiles; tile += n_waves) {
-        const bool uf = tile < uf_tiles, bias = tile >= uf_tiles + if_tiles;
-        const int tt = uf ? tile : (bias ? tile - uf_tiles - if_tiles : tile - uf_tiles);
-        lds_float *table = uf ? t_v_uf : (bias ? t_w_if : t_v_if);
-        const lds_float *coef = uf ? st_xu : st_dx, *vec = uf ? st_dij : st_nvu;
-        const int n_rows = uf ? a.n_uf : a.n_if;
-        const int width = bias ? 1 : F;
-        const int r0 = bias ? tt * 16 : (tt / f_tiles) * 16, f0 = bias ? 0 : (tt % f_tiles) * 16;
-        // A operand: lane l holds c[g = k0 + (l >> 4)][r = r0 + (l & 15)];  B operand: vec[g = k0 + (l >> 4)][f = f0 + (l & 15)]
-        const int r16 = lane & 15, r = r0 + r16, f = f0 + r16, kk = lane >> 4;
-        f32x4 acc = {0};
-        int touches = 0;
-        float grow = 1.0f;                                  // keep^-(touching groups before this k-step)
-        for (int k0 = 0; k0 < n_groups; k0 += 4) {
-            const int g = k0 + kk;
-            float x = 0.0f, vb = 0.0f;
-            bool touch = false;
-            if (g < n_groups) {
-                if (r < n_rows) {
-                    x = coef[g * n_rows + r];
-                    touch = bias ? st_row[3 * g + 2] != 0.0f : x != 0.0f;
-                }
-                if (f < width) vb = bias ? 1.0f : vec[g * F + f];
-            }
-            // the four lanes of a row (groups k0 .. k0+3) learn from one ballot which of them touch it
-            const unsigned long long m = __ballot(touch) >> r16;
-            const int b0 = (int)(m & 1), b1 = (int)((m >> 16) & 1), b2 = (int)((m >> 32) & 1), b3 = (int)((m >> 48) & 1);
-            const int before = (kk > 0 ? b0 : 0) + (kk > 1 ? b1 : 0) + (kk > 2 ? b2 : 0), all = b0 + b1 + b2 + b3;
-            float ca = 0.0f;
-            if (touch)
-                ca = st_row[3 * g] * st_row[3 * g + 1] * x * grow * (before == 0 ? inv1 : before == 1 ? inv2 : before == 2 ? inv3 : inv4);
-            grow *= all == 0 ? 1.0f : all == 1 ? inv1 : all == 2 ? inv2 : all == 3 ? inv3 : inv4;
-            touches += all;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca, vb, acc, 0, 0, 0);
-        }
-        float shrink = 1.0f, b = keep;                      // keep ^ touches(r), exact for one touch
-        for (int n = touches; n; n >>= 1) { if (n & 1) shrink *= b; b *= b; }
-        // C/D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row_l = 4 * kk + reg;
-            const float sh = __shfl(shrink, row_l);
-            if (r0 + row_l < n_rows && f < width) {
-                lds_float *t = table + (r0 + row_l) * width + f;
-                *t = sh * (*t + eta_f * acc[reg]);
-            }
-        }
-    }
-}
 
 // wavefront reduction of the log-likelihood / draw counters, one atomic each per wavefront
 __device__ __forceinline__ void flush_counters(const SgdArgs &a, double ll_acc, unsigned draw_acc) {
@@ -1105,46 +1001,19 @@ static __global__ void __launch_bounds__(256) hot_reduce_kernel(const SgdArgs a)
 // the window ends every stripe row is published with ONE set of atomics however many updates it received -- with
 // 64 groups x 32 rows on 256 stripe rows about eight.  That takes the negative item's 4 + 1 memory-side atomic requests per
 // update (of ~10, the kernel's bound: DESIGN.md section 7) down to ~0.6, and the negative's row reads from 5 to ~0.6.
-template <int G, int KPL, bool FEAT, bool FRESH, bool HOT = false, bool WARPB = true, bool STRIPE = false>
-__global__ void __launch_bounds__((FEAT || HOT || STRIPE) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
+template <int G, int KPL, bool FRESH, bool HOT = false, bool WARPB = true, bool STRIPE = false>
+__global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
+    constexpr bool FEAT = false;        // (models with features run sgd_features_kernel)
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
     if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
     const int F = a.n_factors;
-    // feature tables: this workgroup's replica in LDS (see SgdArgs::feat_snapshot)
     extern __shared__ __attribute__((aligned(16))) float lds_tables[];
-    const int n_tab = FEAT ? (a.n_uf + a.n_if) * F + a.n_if : 0;
-    if constexpr (FEAT) {
-        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = a.feat_snapshot[k];
-        __syncthreads();
-    }
     lds_float *lds = (lds_float *)lds_tables;
-    typedef RowStep<G, KPL, false, FEAT, true, FRESH, FEAT, HOT, WARPB, STRIPE> Step;
-    Step step = [&]() {
-        if constexpr (FEAT) return Step(a, sub, lds, lds + a.n_uf * F, lds + (a.n_uf + a.n_if) * F);
-        else return Step(a, sub, a.v_uf, a.v_if, a.w_if);
-    }();
-    const int wg_groups = blockDim.x / G;
-    // two staging areas, used alternately: while some wavefronts still apply step s from one, the others stage step s+1 in
-    // the other -- one barrier per step (see the loop)
-    const int n_stage = wg_groups * (3 + 2 * F + a.n_uf + a.n_if);
-    auto set_stage = [&](int buf) {
-        step.st_row = lds + n_tab + buf * n_stage;
-        step.st_nvu = step.st_row + 3 * wg_groups;
-        step.st_dij = step.st_nvu + wg_groups * F;
-        step.st_xu = step.st_dij + wg_groups * F;
-        step.st_dx = step.st_xu + wg_groups * a.n_uf;
-    };
-    int stage_buf = 0;
-    if constexpr (FEAT) {
-        step.wg_group = threadIdx.x / G;
-        set_stage(0);
-        // idle groups enter the batch product with coefficient 0: their staged vectors must at least be finite
-        for (int k = threadIdx.x; k < 2 * n_stage; k += blockDim.x) lds_tables[n_tab + k] = 0.0f;
-        __syncthreads();
-    }
+    typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, WARPB, STRIPE> Step;
+    Step step(a, sub, a.v_uf, a.v_if, a.w_if);
     if constexpr (HOT) {
         // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] touch counters
         const int n_acc = a.n_hot * (F + 2);
@@ -1276,7 +1145,6 @@ __global__ void __launch_bounds__((FEAT || HOT || STRIPE) ? 1024 : 256) sgd_segm
             if (!a.hot_direct && iter % n_waves == wave)
                 for (int line = blockIdx.x; line < hot_lines(a); line += gridDim.x) hot_sweep_line(a, line);
         }
-        const bool works = active;
         if (active && !have) {
             const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
             const int4 d = a.seg_desc[seg];
@@ -1331,19 +1199,6 @@ __global__ void __launch_bounds__((FEAT || HOT || STRIPE) ? 1024 : 256) sgd_segm
                 sp += stride;
                 active = sp < a.pos_end;
             }
-        } else if constexpr (FEAT) {
-            step.stage_idle();
-        }
-        if constexpr (FEAT) {
-            // With features the workgroup advances in lock-step, one barrier per step: behind it every group's row of this
-            // step is staged, and every wavefront has finished applying the previous step (it did so before it started
-            // this one), so the other staging area is free again.  The batch is applied while faster wavefronts already
-            // work on their next rows -- they may read a table row half-way through its update, which is Hogwild as usual.
-            if (!__syncthreads_or(works)) break;
-            apply_feature_batch(a, step.t_v_uf, step.t_v_if, step.t_w_if, step.st_row, step.st_nvu, step.st_dij, step.st_xu,
-                                step.st_dx, wg_groups);
-            stage_buf ^= 1;
-            set_stage(stage_buf);
         }
     }
     if constexpr (HOT) {          // publish whatever is still pending
@@ -1358,25 +1213,200 @@ __global__ void __launch_bounds__((FEAT || HOT || STRIPE) ? 1024 : 256) sgd_segm
             if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + k, d);
         }
     }
-    if constexpr (FEAT) {
-        __syncthreads();
-        if (a.feat_select_wg < 0 || a.feat_select_wg == (int)blockIdx.x) {
-            for (int k = threadIdx.x; k < n_tab; k += blockDim.x) {
-                float *dst = k < a.n_uf * F ? a.v_uf + k : (k < (a.n_uf + a.n_if) * F ? a.v_if + (k - a.n_uf * F) : a.w_if + (k - (a.n_uf + a.n_if) * F));
-                if (a.feat_select_wg >= 0) {
-                    *dst = lds_tables[k];
-                } else {
-                    const float d = (lds_tables[k] - a.feat_snapshot[k]) * a.feat_merge;
-                    if (d != 0.0f) atomic_add_f32(dst, d);
+    flush_counters(a, ll_acc, draw_acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// features kernel (production Hogwild for models with user / item features)
+//
+// The dense feature tables v_uf [P,F], v_if [Q,F], w_if [Q] are touched by EVERY update (rankfm/_rankfm.pyx:283-286, 313-326),
+// and each touch shrinks the touched rows by 2 beta eta: in the sequential algorithm they are an exponential moving average of
+// the last ~1 / (2 beta eta) = 50-170 updates' gradients, i.e. they forget within a tiny fraction of an epoch.  16 k
+// interactions in flight cannot share such rows Hogwild-style (thousands of stale shrinks diverge), and per-workgroup replicas
+// that evolve independently and are merged now and then drift apart: the item biases, which every workgroup shares, are then
+// pulled by 256 different w_if / v_if at once (measured on config 4's share: log-likelihood +6 %, |w_i| +14 % against the
+// sequential oracle, and the more replicas the worse: profiles/r02_notes.md).  So the tables are trained by ONE sequential stream
+// and read, coherently, by everybody:
+//   * the TABLE TRAINER is workgroup 0.  Each of its row groups samples an interaction of the rank's data at random, scores it
+//     exactly like a regular step and computes the step's updated v_u and v_i - v_j WITHOUT storing them (the rows themselves
+//     are trained when their own turn comes) and stages them in LDS; then the reference's table updates of the 64 interactions
+//     are applied in order, all table rows in parallel (the rows of the tables do not read each other), on the workgroup's LDS
+//     master copy, which is published to the weight arrays in memory after every step -- a few million rows per second, i.e.
+//     hundreds of table memories per epoch.  A sequential SGD stream on a uniform sample of the rows: the same process that drives the
+//     tables in the reference, with the same memory and the same noise level (that matters: on random tags the tables ARE
+//     mostly noise, and averaging replicas visibly shrinks them);
+//   * every other workgroup runs the usual asynchronous row loop (user segments, v_u in registers, atomics for v_i / w_i) with
+//     the tables as a READ-ONLY copy in its workgroup's LDS, refreshed from memory every few rows by the wavefronts in turn
+//     (system-scope loads: the per-XCD L2s are not coherent, and a 16 KB table that is re-read all the time would otherwise
+//     never leave them).  No lock-step, no barrier in the loop.
+// One group alone (debug_flags bit 0) does both in the reference's order -- the sequential form the parity tests pin.
+// ---------------------------------------------------------------------------------------------
+template <int G, int KPL, bool FRESH, bool WARPB>
+__global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
+    constexpr int GPW = 64 / G;                                    // row groups per wavefront
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int sub = lane % G;
+    const int F = a.n_factors;
+    extern __shared__ __attribute__((aligned(16))) float lds_tables[];
+    lds_float *lds = (lds_float *)lds_tables;
+    const int n_uf_f = a.n_uf * F, n_if_f = a.n_if * F, n_tab = n_uf_f + n_if_f + a.n_if;
+    auto table_ptr = [&](int k) { return k < n_uf_f ? a.v_uf + k : (k < n_uf_f + n_if_f ? a.v_if + (k - n_uf_f) : a.w_if + (k - n_uf_f - n_if_f)); };
+    for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
+    __syncthreads();
+    unsigned int *done_counter = a.error_flags + 3;                // regular workgroups that have finished this launch
+
+    if (!a.single_group && blockIdx.x == 0) {
+        // ---- the table trainer
+        typedef RowStep<G, KPL, false, true, true, true, true, false, WARPB, false, 1> Train;
+        Train step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
+        const int gid = threadIdx.x / G, gpb = blockDim.x / G;
+        const int n_slot = 1 + 2 * F + a.n_uf + a.n_if;            // staged step of one interaction (RowStep::stage)
+        lds_float *stage = lds + n_tab;
+        __shared__ int stop;
+        double ll_unused = 0.0;
+        unsigned draws_unused = 0;
+        for (uint32_t n = 0;; ++n) {
+            if (threadIdx.x == 0)
+                stop = __hip_atomic_load(done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= gridDim.x - 1 ? 1 : 0;
+            __syncthreads();
+            if (stop) break;
+            // a uniformly random row: a random segment (accepted with probability length / 32) and a random row of it
+            uint32_t h = rfm_mix32(a.epoch_key ^ rfm_mix32((n * gpb + gid) * 0x9E3779B9U + 0x3C6EF372U + a.launch_index));
+            int4 d;
+            for (;;) {
+                d = a.seg_desc[rfm_draw_to_item(h, (uint32_t)a.n_segments)];
+                h = rfm_mix32(h + 0x632BE5ABU);
+                if ((int)rfm_draw_to_item(h, (uint32_t)kSegmentRows) < d.z) break;
+                h = rfm_mix32(h + 0x7F4A7C15U);
+            }
+            h = rfm_mix32(h ^ 0x85EBCA6BU);
+            const int32_t u = d.x, pos = d.y + (int32_t)rfm_draw_to_item(h, (uint32_t)d.z);
+            const int32_t i = a.csr_items[pos];
+            const float sw = a.sw_csr[pos];
+            const int64_t lo = a.csr_off[u], hi = a.csr_off[u + 1];
+            float vu[KPL];
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) vu[k] = (sub + G * k < F) ? load_f32<true>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+            step.stage = stage + (size_t)gid * n_slot;
+            step(rfm_mix32(h ^ 0xC2B2AE35U), u, i, sw, lo, hi, vu, ll_unused, draws_unused);
+            __syncthreads();
+            // Apply the staged steps.  Within one interaction the table rows do not read each other, so the reference's
+            // sequential update of the tables over the gpb staged interactions (rankfm/_rankfm.pyx:283-286, 313-326) is, for each
+            // table ROW, a walk over the interactions that touch it -- all rows at once, one 16-lane group per row with the row
+            // in registers, plain read and write.
+            const float eta_f = a.eta, reg_b = a.reg_b;
+            for (int r = gid; r < a.n_uf + a.n_if; r += gpb) {
+                const bool uf = r < a.n_uf;
+                if (uf ? !a.has_uf : !a.has_if) continue;
+                lds_float *row = lds + (size_t)r * F;                                  // v_uf rows, then v_if rows
+                const int xoff = 1 + 2 * F + r, voff = uf ? 1 + F : 1;                   // coefficient; vector: v_i - v_j | v_u
+                float tr[KPL];
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) tr[k] = (sub + G * k < F) ? row[sub + G * k] : 0.0f;
+                for (int s2 = 0; s2 < gpb; ++s2) {
+                    const lds_float *st = stage + (size_t)s2 * n_slot;
+                    const float x = st[xoff];
+                    if (x == 0.0f) continue;                                            // rows the interaction does not touch keep their value
+                    const float c = st[0] * x;
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (sub + G * k < F) tr[k] += eta_f * (c * st[voff + sub + G * k] - reg_b * tr[k]);
                 }
+#pragma unroll
+                for (int k = 0; k < KPL; ++k)
+                    if (sub + G * k < F) row[sub + G * k] = tr[k];
+            }
+            if (a.has_if)
+                for (int q = threadIdx.x; q < a.n_if; q += blockDim.x) {               // w_if: every interaction shrinks every q
+                    float w = lds[n_uf_f + n_if_f + q];
+                    for (int s2 = 0; s2 < gpb; ++s2) {
+                        const lds_float *st = stage + (size_t)s2 * n_slot;
+                        w += eta_f * (st[0] * st[1 + 2 * F + a.n_uf + q] - reg_b * w);
+                    }
+                    lds[n_uf_f + n_if_f + q] = w;
+                }
+            __syncthreads();
+            // publish the master copy (write-through to memory)
+            for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
+                __hip_atomic_store(table_ptr(k), lds_tables[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // for the next launch
+        return;
+    }
+
+    // ---- regular workgroups (1 .. grid-1): the asynchronous row loop of sgd_segments_kernel, tables read-only
+    const int64_t gpb = blockDim.x / G;
+    const int64_t group = a.single_group ? (int64_t)threadIdx.x / G : ((int64_t)blockIdx.x - 1) * gpb + threadIdx.x / G;
+    int64_t n_groups = a.single_group ? gpb : ((int64_t)gridDim.x - 1) * gpb;
+    if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 0> Reg;
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 2> Both;
+    Reg step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
+    Both both(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
+    double ll_acc = 0.0;
+    unsigned draw_acc = 0;
+    int64_t sp = a.pos_begin + (a.single_group ? 0 : group);
+    const int64_t stride = a.single_group ? 1 : n_groups;
+    bool active = sp < a.pos_end && (a.single_group ? group == 0 : group < n_groups);
+    bool have = false;
+    int32_t u = 0, begin = 0, len = 0, t = 0, len_bits = 0;
+    uint32_t seg_key = 0;
+    int64_t lo = 0, hi = 0;
+    float vu[KPL], vu0[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
+    constexpr int kRefreshEvery = 4;                               // rows between table refreshes of a workgroup
+    for (int iter = 0; __any(active); ++iter) {
+        const int every = a.update_mode == 6 ? 1 : kRefreshEvery;       // (experiment: refresh every row)
+        if (!a.single_group && a.update_mode != 5 && iter % every == 0 && (iter / every) % n_waves == wave) {
+            // this wavefront's turn to bring the workgroup's copy up to date (readers may see a row half old, half new:
+            // both are tables the trainer published)
+            for (int k = lane; k < n_tab; k += 64)
+                lds_tables[k] = __hip_atomic_load(table_ptr(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (active && !have) {
+            const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
+            const int4 d = a.seg_desc[seg];
+            u = d.x; begin = d.y; len = d.z;
+            lo = a.csr_off[u]; hi = a.csr_off[u + 1];
+            len_bits = (int32_t)rfm_perm_bits((uint32_t)len);
+            seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                vu[k] = vu0[k];
+            }
+            t = 0;
+            have = true;
+        }
+        if (active) {
+            const int32_t pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);
+            const int32_t i = a.csr_items[pos];
+            const float sw = a.sw_csr[pos];
+            if (a.single_group) both(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+            else step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+            if (++t == len) {
+#pragma unroll
+                for (int k = 0; k < KPL; ++k)
+                    if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                have = false;
+                sp += stride;
+                active = sp < a.pos_end;
             }
         }
+    }
+    if (!a.single_group) {
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (a.single_group) {             // the one group trained the tables in its LDS: store them
+        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) *table_ptr(k) = lds_tables[k];
     }
     flush_counters(a, ll_acc, draw_acc);
 }
 
 // host-side launcher table (rfm_sgd_inst_*.hip): [0..3] rows kernel {hogwild, hogwild+feat, serial, serial+feat},
-// [4..7] segments kernel {plain, feat, fresh, fresh+feat}, [8..9] segments kernel with hot-row accumulators {plain, fresh},
+// [4..7] segments kernel {plain, features kernel, fresh, features kernel fresh}, [8..9] segments kernel with hot-row accumulators {plain, fresh},
 // [10..13] segments kernel with negative stripes {plain, fresh, hot, hot+fresh}
 typedef void (*sgd_launch_fn)(const SgdArgs &, int grid, hipStream_t);
 

@@ -167,15 +167,28 @@ def test_hogwild_warp_statistical_parity(oracle):
 
 
 def test_hogwild_features_statistical_parity(oracle):
-    """Dense feature tables are touched by every update, so they cannot be Hogwild rows: each workgroup trains its own LDS
-    replica and one replica per launch window is kept (DESIGN.md "feature tables").  On this problem the tags are random,
-    i.e. the tables hold mostly gradient noise with a memory of ~1/(2*beta*eta) = 50 rows: their values are not comparable
-    run to run (two seeds of the reference itself differ), only their scale is.  The learned factors and the
-    log-likelihood must still track the sequential oracle -- to 10 % / 2 % here, since the replicas' noise reaches v_u and
-    v_i through the feature projections independently per workgroup instead of coherently."""
+    """Dense feature tables are touched by every update, so they cannot be Hogwild rows: one workgroup (the table trainer of
+    sgd_features_kernel) trains them sequentially on a uniform sample of the rows and every other workgroup reads a copy
+    (DESIGN.md section 5.3).  On this problem the tags are random, i.e. the tables hold mostly gradient noise with a memory of
+    ~1/(2*beta*eta) = 50 rows: their values are not comparable run to run (two seeds of the reference itself differ), only
+    their scale is.  What must track the sequential oracle is the MODEL: per-epoch log-likelihood within 2 %, predicted
+    utilities of random (user, item) pairs correlated > 0.97 with the oracle model's.  The fit is split between item biases,
+    factors and tables a little differently (8 active tags x the mean table row acts as a bias the item biases can carry
+    instead), so the factor norms agree less tightly than without features: measured v_u -5.5 %, v_i -11 %, w_i +8.5 % here
+    (bounds 8 / 13 / 12 %), and within 0.2 % once both sides start an epoch from the same weights (test_gpu_configs.py)."""
     prob = _problem(U=3000, I=2000, N=120_000, F=32, seed=21, n_uf=8, n_if=8)
     g, rep, o, out = _both(oracle, prob, max_samples=1, epochs=2)
-    _assert_statistical_parity(g, rep, o, out, names=("v_u", "v_i", "w_i"), norm_tol=0.10, corr=0.85)
+    np.testing.assert_allclose(rep["log_likelihood"], out["ll"], rtol=0.02)
+    for k, tol in (("v_u", 0.08), ("v_i", 0.13), ("w_i", 0.12)):
+        r = np.linalg.norm(g[k]) / np.linalg.norm(o[k])
+        assert abs(r - 1.0) <= tol, "|%s| gpu / oracle = %.4f" % (k, r)
+    rng = np.random.default_rng(0)
+    pairs = np.stack([rng.integers(0, 3000, 50_000), rng.integers(0, 2000, 50_000)], 1).astype(np.float32)
+    x_uf, x_if = prob[3], prob[4]
+    sg = oracle.predict(pairs, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"])
+    so = oracle.predict(pairs, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"])
+    c = np.corrcoef(sg, so)[0, 1]
+    assert c > 0.97, "correlation of predicted utilities with the oracle model's %.4f" % c
     for k in ("v_uf", "v_if", "w_if"):
         assert np.isfinite(g[k]).all()
         assert 0.33 < np.linalg.norm(g[k]) / np.linalg.norm(o[k]) < 3.0, k
