@@ -1159,8 +1159,8 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
             }
             t = 0;
             have = true;
+            step.load_ulist(lo, hi);
             if constexpr (STRIPE) {
-                step.load_ulist(lo, hi);
                 // the segment's rows in visiting order, held across the lanes (row t in lane t % G, register t / G): item,
                 // sample weight and CSR position come out of registers for the rest of the segment
 #pragma unroll
