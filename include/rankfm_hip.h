@@ -191,6 +191,13 @@ int rfm_recommend_host(const rfm_model_view *host_model, int64_t n_rec_users, co
                        const int64_t *csr_offsets, const int32_t *csr_items, int32_t n_rec, int32_t filter_previous,
                        float *rec_items, int device);
 
+/* ---- `similar_items` / `similar_users` (rankfm/rankfm.py:405-428 / 431-454): the n rows whose latent representation
+ * v[r] + x[r] . v_f has the largest dot product with that of row `index`, the row itself excluded; out: float32 [n] row
+ * indexes by descending similarity.  kind: RFM_SIMILAR_ITEMS (v_i, x_if, v_if) or RFM_SIMILAR_USERS (v_u, x_uf, v_uf). ---- */
+#define RFM_SIMILAR_ITEMS 0
+#define RFM_SIMILAR_USERS 1
+int rfm_similar_host(const rfm_model_view *host_model, int32_t kind, int32_t index, int32_t n, float *out, int device);
+
 #ifdef __cplusplus
 }
 #endif

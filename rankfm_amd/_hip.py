@@ -81,7 +81,7 @@ class ModelView(C.Structure):
 EXPORTS = (
     "rfm_abi_version", "rfm_status_string", "rfm_last_error", "rfm_device_count", "rfm_fit_supported",
     "rfm_fit_workspace_bytes", "rfm_fit_device", "rfm_fit_host", "rfm_predict_device", "rfm_predict_host",
-    "rfm_recommend_device", "rfm_recommend_workspace_bytes", "rfm_recommend_host",
+    "rfm_recommend_device", "rfm_recommend_workspace_bytes", "rfm_recommend_host", "rfm_similar_host",
 )
 
 _lib = None
@@ -136,6 +136,8 @@ def lib():
     L.rfm_recommend_host.restype = C.c_int
     L.rfm_recommend_host.argtypes = [C.POINTER(ModelView), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_void_p, C.c_int]
+    L.rfm_similar_host.restype = C.c_int
+    L.rfm_similar_host.argtypes = [C.POINTER(ModelView), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
     if L.rfm_abi_version() != ABI_VERSION:
         raise EngineUnavailable("librankfm_hip.so ABI %d != binding ABI %d: rebuild" % (L.rfm_abi_version(), ABI_VERSION))
     _lib = L

@@ -260,3 +260,14 @@ def _recommend(users, user_items, n_items, filter_previous, x_uf, x_if, w_i, w_i
                                        default_device() if device is None else int(device))
     _hip.raise_for_status(rc)
     return rec
+
+
+def _similar(kind, index, n, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if, *, device=None):
+    """device side of `similar_items` (kind 0) / `similar_users` (kind 1), rankfm/rankfm.py:405-454: float32 [n] row indexes
+    by descending dot product of the latent representations, the query row excluded"""
+    mv = _model_view(x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if)
+    out = np.empty(int(n), dtype=np.float32)
+    rc = _hip.lib().rfm_similar_host(C.byref(mv), int(kind), int(index), int(n), _ptr(out),
+                                     default_device() if device is None else int(device))
+    _hip.raise_for_status(rc)
+    return out

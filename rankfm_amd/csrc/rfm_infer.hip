@@ -10,6 +10,7 @@
 // users as one f32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) followed by a block-wide top-n.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/rankfm_hip.h"
@@ -226,6 +227,142 @@ __global__ void __launch_bounds__(256) topn_kernel(const float *__restrict__ use
     }
 }
 
+// Threshold selection for n_rec <= kTopLocal (the usual top-10): exact, two cheap passes over the score row instead of n_rec.
+//   pass 1  the row is cut into up to kSegs interleaved segments (segment s = elements s, s + nseg, ...: coalesced); every
+//           segment's best element goes to LDS; n_rec rounds of block-wide argmax over those maxima leave T = the n_rec-th
+//           best segment maximum.  At least n_rec elements rank at or above T, so the top n_rec all do;
+//   pass 2  every element ranking at or above T is appended to an LDS candidate list -- at most (n_rec - 1) x segment
+//           length + 1 of them, typically ~n_rec -- and n_rec rounds of argmax over the list give the ranking.
+// Same ordering rules as topn_kernel: descending utility, among equals the larger index first, NaN never wins, observed items
+// knocked out.
+constexpr int kTopLocal = 16;
+constexpr int kSegs = 4096, kCands = 4096;
+
+__device__ __forceinline__ bool ranks_before(float v, int i, float w, int j) {      // (v, i) ranks before (w, j)
+    return v > w || (v == w && i > j);
+}
+
+// block-wide argmax of (val, idx) pairs held one per thread; result broadcast to every thread
+__device__ __forceinline__ void block_best(float &v, int &i, float *w_val, int *w_idx) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int msk = 32; msk > 0; msk >>= 1) {
+        const float ov = __shfl_xor(v, msk);
+        const int oi = __shfl_xor(i, msk);
+        if (oi >= 0 && (i < 0 || ranks_before(ov, oi, v, i))) { v = ov; i = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { w_val[wid] = v; w_idx[wid] = i; }
+    __syncthreads();
+    v = w_val[0]; i = w_idx[0];
+    for (int w = 1; w < 4; ++w)
+        if (w_idx[w] >= 0 && (i < 0 || ranks_before(w_val[w], w_idx[w], v, i))) { v = w_val[w]; i = w_idx[w]; }
+}
+
+__global__ void __launch_bounds__(256) topn_select_kernel(const float *__restrict__ users, long long user_begin, int n_items,
+                                                          const int64_t *__restrict__ csr_off, const int32_t *__restrict__ csr_items,
+                                                          int filter_previous, int n_rec, int skip_index, float *__restrict__ scores,
+                                                          float *__restrict__ rec) {
+    __shared__ float s_val[kSegs];          // pass 1: segment maxima; pass 2: candidates
+    __shared__ int s_idx[kSegs];
+    __shared__ float w_val[4];
+    __shared__ int w_idx[4];
+    __shared__ int n_cand;
+    const long long slot = blockIdx.x;
+    const float uf = users ? users[user_begin + slot] : 0.0f;
+    float *out = rec + (size_t)(user_begin + slot) * n_rec;
+    if (isnan(uf)) {                                                      // rankfm/_rankfm.pyx:435-437
+        for (int k = threadIdx.x; k < n_rec; k += blockDim.x) out[k] = __uint_as_float(0x7fc00000u);
+        return;
+    }
+    float *row = scores + (size_t)slot * n_items;
+    if (filter_previous) {                                                // rankfm/_rankfm.pyx:450-451
+        const int u = (int)uf;
+        for (int64_t k = csr_off[u] + threadIdx.x; k < csr_off[u + 1]; k += blockDim.x) row[csr_items[k]] = -INFINITY;
+    }
+    if (threadIdx.x == 0) n_cand = 0;
+    __syncthreads();
+    const int seglen = (n_items + kSegs - 1) / kSegs, nseg = (n_items + seglen - 1) / seglen;
+    // ---- pass 1: segment maxima
+    for (int sg = threadIdx.x; sg < nseg; sg += blockDim.x) {
+        float bv = -INFINITY;
+        int bi = -1;
+        for (int j = 0; j < seglen; ++j) {
+            const int i = sg + j * nseg;
+            if (i >= n_items) break;
+            const float v = row[i];
+            if (i != skip_index && v > -INFINITY && (bi < 0 || ranks_before(v, i, bv, bi))) { bv = v; bi = i; }
+        }
+        s_val[sg] = bv; s_idx[sg] = bi;
+    }
+    __syncthreads();
+    // the n_rec-th best segment maximum (selected maxima are struck out of the LDS copy as they are found)
+    float tv = -INFINITY;
+    int ti = -1;
+    for (int r = 0; r < n_rec; ++r) {
+        float bv = -INFINITY;
+        int bi = -1, bs = -1;
+        for (int sg = threadIdx.x; sg < nseg; sg += blockDim.x)
+            if (s_idx[sg] >= 0 && (bi < 0 || ranks_before(s_val[sg], s_idx[sg], bv, bi))) { bv = s_val[sg]; bi = s_idx[sg]; bs = sg; }
+        float gv = bv;
+        int gi = bi;
+        block_best(gv, gi, w_val, w_idx);
+        if (gi < 0) break;                                                // fewer than n_rec rankable elements
+        tv = gv; ti = gi;
+        if (bi == gi && bs >= 0) s_idx[bs] = -1;                           // (indexes are unique: exactly one thread strikes)
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- pass 2: everything that ranks at or above the threshold
+    if (ti >= 0) {
+        for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+            const float v = row[i];
+            if (i == skip_index || !(v > -INFINITY)) continue;
+            if (i == ti || ranks_before(v, i, tv, ti)) {
+                const int c = atomicAdd(&n_cand, 1);
+                if (c < kCands) { s_val[c] = v; s_idx[c] = i; }
+            }
+        }
+    }
+    __syncthreads();
+    const int nc = n_cand < kCands ? n_cand : kCands;
+    for (int r = 0; r < n_rec; ++r) {
+        float bv = -INFINITY;
+        int bi = -1, bc = -1;
+        for (int c = threadIdx.x; c < nc; c += blockDim.x)
+            if (s_idx[c] >= 0 && (bi < 0 || ranks_before(s_val[c], s_idx[c], bv, bi))) { bv = s_val[c]; bi = s_idx[c]; bc = c; }
+        float gv = bv;
+        int gi = bi;
+        block_best(gv, gi, w_val, w_idx);
+        if (threadIdx.x == 0) out[r] = gi >= 0 ? (float)gi : __uint_as_float(0x7fc00000u);
+        if (gi >= 0 && bi == gi && bc >= 0) s_idx[bc] = -1;
+        __syncthreads();
+    }
+}
+
+// similar_items / similar_users (rankfm/rankfm.py:405-454): latent representation rep[r] = v[r] + x[r] . v_f of every row, its
+// dot product with the query row's representation -> sims [n_rows]; the ranking is topn_select_kernel with the query skipped.
+__global__ void __launch_bounds__(256) similarity_kernel(const float *__restrict__ v, const float *__restrict__ x, const float *__restrict__ vf,
+                                                         int has_features, int n_rows, int n_feat, int F, int query, float *__restrict__ sims) {
+    const int sub = threadIdx.x & (kGroup - 1);
+    const int group = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup, n_groups = (gridDim.x * blockDim.x) / kGroup;
+    for (int r = group; r < n_rows; r += n_groups) {
+        float part = 0.0f;
+        for (int f = sub; f < F; f += kGroup) {
+            float a = v[(size_t)r * F + f], q = v[(size_t)query * F + f];
+            if (has_features)
+                for (int p = 0; p < n_feat; ++p) {
+                    const float t = vf[(size_t)p * F + f];
+                    a += x[(size_t)r * n_feat + p] * t;
+                    q += x[(size_t)query * n_feat + p] * t;
+                }
+            part += a * q;
+        }
+        part = group16_sum(part);
+        if (sub == 0) sims[r] = part;
+    }
+}
+
 static int check_model(const rfm_model_view *m) {
     if (!m || m->n_users < 1 || m->n_items < 1 || m->n_factors < 1 || m->n_user_features < 1 || m->n_item_features < 1)
         return RFM_ERR_BAD_ARG;
@@ -335,8 +472,13 @@ int rfm_recommend_device(const rfm_model_view *m, int64_t n_users, const float *
         build_ueff_kernel<<<dim3(64), dim3(256), 0, stream>>>(*m, users, u0, (int)nu, kp, ueff);
         scores_mfma_kernel<<<dim3((unsigned)((I + 63) / 64), (unsigned)((nu + 63) / 64)), dim3(256), 0, stream>>>(
             ueff, veff, bias, (int)nu, m->n_items, kp, scores);
-        topn_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, m->n_items, csr_off, csr_items, filter_previous,
-                                                                   n_rec, scores, rec);
+        // (threshold selection holds its candidates in LDS: worst case (n_rec - 1) x segment length + 1 of them)
+        if (n_rec <= kTopLocal && (long long)(n_rec - 1) * ((m->n_items + kSegs - 1) / kSegs) + 1 <= kCands)
+            topn_select_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, m->n_items, csr_off, csr_items, filter_previous,
+                                                                              n_rec, -1, scores, rec);
+        else
+            topn_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, m->n_items, csr_off, csr_items, filter_previous,
+                                                                       n_rec, scores, rec);
     }
     return hipGetLastError() == hipSuccess ? RFM_OK : RFM_ERR_HIP;
 }
@@ -369,6 +511,45 @@ int rfm_recommend_host(const rfm_model_view *hm, int64_t n_users, const float *u
                                   n_rec, filter_previous, (float *)allocs[11], allocs[12], ws, nullptr);
     if (rc == RFM_OK && hipMemcpy(rec, allocs[11], sizes[3], hipMemcpyDeviceToHost) != hipSuccess) rc = RFM_ERR_HIP;
     free_all(allocs, 13);
+    return rc;
+}
+
+int rfm_similar_host(const rfm_model_view *hm, int32_t kind, int32_t index, int32_t n, float *out, int device) {
+    int rc = check_model(hm);
+    if (rc != RFM_OK) return rc;
+    const int rows = kind == RFM_SIMILAR_ITEMS ? hm->n_items : hm->n_users;
+    if ((kind != RFM_SIMILAR_ITEMS && kind != RFM_SIMILAR_USERS) || index < 0 || index >= rows || n < 1 || n > rows - 1 || !out)
+        return RFM_ERR_BAD_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return RFM_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RFM_ERR_HIP;
+    const bool items = kind == RFM_SIMILAR_ITEMS;
+    const int F = hm->n_factors, nf = items ? hm->n_item_features : hm->n_user_features;
+    const int has = items ? hm->has_item_features : hm->has_user_features;
+    const float *hv = items ? hm->v_i : hm->v_u, *hx = items ? hm->x_if : hm->x_uf, *hvf = items ? hm->v_if : hm->v_uf;
+    void *a[6] = {nullptr};
+    const size_t bytes[6] = {sizeof(float) * (size_t)rows * F, sizeof(float) * (size_t)rows * nf, sizeof(float) * (size_t)nf * F,
+                             sizeof(float) * (size_t)rows, sizeof(float) * (size_t)n, 0};
+    const void *src[3] = {hv, hx, hvf};
+    for (int k = 0; k < 5 && rc == RFM_OK; ++k) {
+        if (hipMalloc(&a[k], bytes[k]) != hipSuccess) rc = RFM_ERR_HIP;
+        else if (k < 3 && hipMemcpy(a[k], src[k], bytes[k], hipMemcpyHostToDevice) != hipSuccess) rc = RFM_ERR_HIP;
+    }
+    if (rc == RFM_OK) {
+        similarity_kernel<<<dim3(512), dim3(256)>>>((const float *)a[0], (const float *)a[1], (const float *)a[2], has, rows, nf, F, index, (float *)a[3]);
+        if (n <= kTopLocal && (long long)(n - 1) * ((rows + kSegs - 1) / kSegs) + 1 <= kCands)
+            topn_select_kernel<<<dim3(1), dim3(256)>>>(nullptr, 0, rows, nullptr, nullptr, 0, n, index, (float *)a[3], (float *)a[4]);
+        else {                                                            // long lists: knock the query out, multi-round selection
+            const float ninf = -INFINITY;
+            if (hipMemcpy((float *)a[3] + index, &ninf, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = RFM_ERR_HIP;
+            const float zero_user = 0.0f;
+            if (hipMalloc(&a[5], sizeof(float)) != hipSuccess || hipMemcpy(a[5], &zero_user, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = RFM_ERR_HIP;
+            if (rc == RFM_OK) topn_kernel<<<dim3(1), dim3(256)>>>((const float *)a[5], 0, rows, nullptr, nullptr, 0, n, (float *)a[3], (float *)a[4]);
+        }
+        if (rc == RFM_OK && hipGetLastError() != hipSuccess) rc = RFM_ERR_HIP;
+    }
+    if (rc == RFM_OK && hipMemcpy(out, a[4], bytes[4], hipMemcpyDeviceToHost) != hipSuccess) rc = RFM_ERR_HIP;
+    free_all(a, 6);
     return rc;
 }
 

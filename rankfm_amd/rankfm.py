@@ -15,7 +15,7 @@ rankfm/_rankfm.pyx:201-212) are O(N) interpreter work.
 import numpy as np
 import pandas as pd
 
-from ._rankfm import DEFAULT_ENGINE, EngineOptions, UserItemsCSR, _fit, _predict, _recommend
+from ._rankfm import _similar, DEFAULT_ENGINE, EngineOptions, UserItemsCSR, _fit, _predict, _recommend
 from .utils import get_data
 
 
@@ -309,23 +309,21 @@ class RankFM():
         return m
 
     def similar_items(self, item_id, n_items=10):
-        """most similar items wrt latent factor space representation (rankfm/rankfm.py:405-428)"""
+        """most similar items wrt latent factor space representation (rankfm/rankfm.py:405-428), ranked on the device"""
         assert item_id in self.item_id.values, "you must select an [item_id] present in the training data"
         assert self.is_fit, "you must fit the model prior to generating similarities"
         idx = int(self.item_to_index.loc[item_id])
-        rep_all = self.v_i + np.dot(self.x_if, self.v_if)
-        sims = np.dot(rep_all, rep_all[idx])
-        order = np.argsort(-sims, kind='stable')
-        order = order[order != idx][:n_items]
+        n = min(int(n_items), len(self.item_idx) - 1)
+        order = _similar(0, idx, n, self.x_uf, self.x_if, self.w_i, self.w_if, self.v_u, self.v_i, self.v_uf, self.v_if,
+                         device=self.engine.device).astype(np.int64)
         return self.index_to_item.values[order]
 
     def similar_users(self, user_id, n_users=10):
-        """most similar users wrt latent factor space representation (rankfm/rankfm.py:431-454)"""
+        """most similar users wrt latent factor space representation (rankfm/rankfm.py:431-454), ranked on the device"""
         assert user_id in self.user_id.values, "you must select an [user_id] present in the training data"
         assert self.is_fit, "you must fit the model prior to generating similarities"
         idx = int(self.user_to_index.loc[user_id])
-        rep_all = self.v_u + np.dot(self.x_uf, self.v_uf)
-        sims = np.dot(rep_all, rep_all[idx])
-        order = np.argsort(-sims, kind='stable')
-        order = order[order != idx][:n_users]
+        n = min(int(n_users), len(self.user_idx) - 1)
+        order = _similar(1, idx, n, self.x_uf, self.x_if, self.w_i, self.w_if, self.v_u, self.v_i, self.v_uf, self.v_if,
+                         device=self.engine.device).astype(np.int64)
         return self.index_to_user.values[order]

@@ -221,7 +221,48 @@ def api_case(name, *, loss, with_features, str_ids, seed=5):
     print("api_%-28s hit_rate@7 %.4f  mrr %.4f  nan scores %d" % (name, out["hit_rate"], out["reciprocal_rank"], int(np.isnan(scores).sum())))
 
 
+def partial_case(name, *, loss, second_with_features, seed=9):
+    """public-API fixture for RESUMED training: fit(A, features) then fit_partial(B[, features]) (rankfm/rankfm.py:269-327).
+    Every call restarts the MT19937 stream at 1492 (rankfm/_rankfm.pyx:182) and its learning-rate schedule at epoch 0; the
+    numpy shuffle stream runs on; the per-user item sets are extended with B's items (rankfm/rankfm.py:170-172); when the
+    second call omits the features, x_uf / x_if are rebuilt as zeros and the feature terms switch off while v_uf / v_if keep
+    their values (rankfm/rankfm.py:286, 199, 211).  B holds every user (the reference raises KeyError otherwise, :172)."""
+    rng = np.random.default_rng(seed)
+    U, I, F = 28, 40, 6
+    A = make_interactions(rng, U, I, 380)
+    B = np.concatenate([np.stack([np.arange(U), rng.integers(0, I, U)], 1), np.stack([rng.integers(0, U, 90), rng.integers(0, I, 90)], 1)])
+    rng.shuffle(B)
+    uid, iid = np.arange(U) * 3 + 100, np.arange(I) * 2 + 1000
+    fa = pd.DataFrame({"user_id": uid[A[:, 0]], "item_id": iid[A[:, 1]]})
+    fb = pd.DataFrame({"user_id": uid[B[:, 0]], "item_id": iid[B[:, 1]]})
+    ufv, ifv = (rng.random((U, 3)) < 0.4).astype(np.float32), (rng.random((I, 4)) < 0.4).astype(np.float32)
+    uf = pd.concat([pd.DataFrame({"user_id": uid}), pd.DataFrame(ufv)], axis=1)
+    itf = pd.concat([pd.DataFrame({"item_id": iid}), pd.DataFrame(ifv)], axis=1)
+    swb = rng.uniform(0.5, 1.5, len(fb)).astype(np.float32)
+    m = RankFM(factors=F, loss=loss, max_samples=5, learning_schedule="invscaling", sigma=0.5)
+    np.random.seed(31)
+    m.fit(fa, uf, itf, epochs=2)
+    w1 = {k: getattr(m, k).copy() for k in WEIGHTS}
+    m.fit_partial(fb, uf if second_with_features else None, itf if second_with_features else None, swb, epochs=2)
+    w2 = {k: getattr(m, k).copy() for k in WEIGHTS}
+    off, items = csr_of(m.user_items, U)
+    out = dict(a_users=fa.user_id.values, a_items=fa.item_id.values, b_users=fb.user_id.values, b_items=fb.item_id.values, b_sw=swb,
+               uf_vals=ufv, if_vals=ifv, user_id=uid, item_id=iid, loss=np.array(loss), factors=np.int32(F), max_samples=np.int32(5),
+               second_with_features=np.int32(int(second_with_features)), interactions_after=m.interactions, csr_off_after=off,
+               csr_items_after=items, x_uf_after=m.x_uf, x_if_after=m.x_if)
+    for k in WEIGHTS:
+        out["first_" + k] = w1[k]
+        out["second_" + k] = w2[k]
+    np.savez_compressed(os.path.join(HERE, "partial_%s.npz" % name), **out)
+    print("partial_%-24s |v_u| %.4f -> %.4f   |v_uf| %.4f -> %.4f" % (name, np.linalg.norm(w1["v_u"]), np.linalg.norm(w2["v_u"]),
+                                                                   np.linalg.norm(w1["v_uf"]), np.linalg.norm(w2["v_uf"])))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "partial":        # only the resumed-training fixtures
+        partial_case("bpr_feat_then_none", loss="bpr", second_with_features=False)
+        partial_case("warp_feat_then_feat", loss="warp", second_with_features=True)
+        sys.exit(0)
     # --- _fit-level fixtures: {bpr, warp} x {no features, features} x {constant, invscaling} (+ sample weights, odd F)
     fit_case("bpr_nofeat_const_f8", U=40, I=60, N=600, F=8, loss="bpr")
     fit_case("bpr_nofeat_inv_f10_sw", U=40, I=60, N=600, F=10, loss="bpr", schedule="invscaling", sample_weights=True, data_seed=1)
@@ -242,3 +283,6 @@ if __name__ == "__main__":
     # --- public-API fixtures
     api_case("bpr_int_nofeat", loss="bpr", with_features=False, str_ids=False)
     api_case("warp_str_feat", loss="warp", with_features=True, str_ids=True)
+    # --- resumed training through the public API
+    partial_case("bpr_feat_then_none", loss="bpr", second_with_features=False)
+    partial_case("warp_feat_then_feat", loss="warp", second_with_features=True)

@@ -72,6 +72,33 @@ def test_resumed_fit_with_a_fixed_seed_does_not_replay_order_and_draws():
         np.testing.assert_allclose(second[k], w[k], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", ["bpr_feat_then_none", "warp_feat_then_feat"])
+def test_fit_then_fit_partial_reproduces_the_reference(case):
+    """resumed training against the reference's own numbers (tests/golden/partial_*.npz): fit(A, features) then
+    fit_partial(B[, features]) in REFERENCE_ENGINE mode -- every call restarts MT19937 at 1492 and its learning-rate schedule at
+    epoch 0 (rankfm/_rankfm.pyx:182, 218-223), numpy's shuffle stream runs on, the item sets are extended, and a second call
+    without features switches the feature terms off while v_uf / v_if keep their values (rankfm/rankfm.py:286, 199, 211)"""
+    from rankfm_amd import REFERENCE_ENGINE, RankFM
+    z = load_golden("partial", case)
+    fa = pd.DataFrame({"user_id": z["a_users"], "item_id": z["a_items"]})
+    fb = pd.DataFrame({"user_id": z["b_users"], "item_id": z["b_items"]})
+    uf = pd.concat([pd.DataFrame({"user_id": z["user_id"]}), pd.DataFrame(z["uf_vals"])], axis=1)
+    itf = pd.concat([pd.DataFrame({"item_id": z["item_id"]}), pd.DataFrame(z["if_vals"])], axis=1)
+    m = RankFM(factors=int(z["factors"]), loss=str(z["loss"]), max_samples=int(z["max_samples"]), learning_schedule="invscaling", sigma=0.5,
+               engine=REFERENCE_ENGINE)
+    np.random.seed(31)
+    m.fit(fa, uf, itf, epochs=2)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(getattr(m, k), z["first_" + k], rtol=1e-4, atol=2e-5, err_msg="first call: " + k)
+    with_feat = bool(int(z["second_with_features"]))
+    own_first = {k: getattr(m, k).copy() for k in ("v_uf", "v_if", "w_if")}
+    m.fit_partial(fb, uf if with_feat else None, itf if with_feat else None, z["b_sw"], epochs=2)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(getattr(m, k), z["second_" + k], rtol=1e-4, atol=2e-5, err_msg="second call: " + k)
+    if not with_feat:                                         # feature terms off: the tables are not touched at all
+        assert all(np.array_equal(getattr(m, k), own_first[k]) for k in own_first)
+
+
 def test_predict_shapes_dtypes_and_cold_start():
     m = _model().fit(INTX)
     s = m.predict(INTX)
@@ -117,6 +144,52 @@ def test_similar_items_and_users():
         m.similar_items(99)
     with pytest.raises(AssertionError):
         m.similar_users(9)
+
+
+@pytest.mark.parametrize("n", [5, 40])
+def test_similar_items_and_users_rank_like_the_reference_formula(n):
+    """similar_items / similar_users on the device (rfm_similar_host: representation v + x . v_f, dot products, top-n with the
+    query row excluded) against the reference's formula (rankfm/rankfm.py:418-426, 444-452) evaluated in numpy; n = 5 takes the
+    single-pass selection, n = 40 the multi-round one"""
+    from rankfm_amd import RankFM, synthetic
+    d = synthetic.make_planted(400, 300, seed=3, mean_degree=40.0, n_tags=6)
+    train = pd.DataFrame(d["train"], columns=["u", "i"])
+    uf = pd.DataFrame(np.column_stack([np.arange(400), d["user_tags"]]))
+    itf = pd.DataFrame(np.column_stack([np.arange(300), d["item_tags"]]))
+    m = RankFM(factors=12, learning_rate=0.03)
+    np.random.seed(1)
+    m.fit(train, uf, itf, epochs=2)
+    for kind, ids, v, x, vf, fn in (("item", m.item_id.values, m.v_i, m.x_if, m.v_if, m.similar_items),
+                                    ("user", m.user_id.values, m.v_u, m.x_uf, m.v_uf, m.similar_users)):
+        rep = v + x @ vf
+        for q in (0, 17, len(ids) - 1):
+            sims = rep @ rep[q]
+            want = np.argsort(-sims, kind="stable")
+            want = want[want != q][:n]
+            got = fn(ids[q], n)
+            assert got.shape == (n,) and ids[q] not in got
+            # equal up to ties / last-ulp differences of the dot products: the similarity of every returned row must be as
+            # large as the n-th best
+            np.testing.assert_allclose(np.sort(sims[np.searchsorted(ids, got)])[::-1], sims[want], rtol=1e-5, atol=1e-6)
+
+
+def test_save_load_round_trip_predicts_and_recommends_identically(tmp_path):
+    """RankFM.save -> RankFM.load (the reference's weight layout + id maps in one .npz): the loaded model's predict / recommend /
+    similar_items on the GPU are bit-equal to the unsaved model's, and training resumes from it"""
+    from rankfm_amd import RankFM
+    m = _model(loss="warp", max_samples=5).fit(INTX, UF, IF, epochs=3)
+    path = str(tmp_path / "model.npz")
+    m.save(path)
+    r = RankFM.load(path)
+    pairs = pd.DataFrame([(10, 1), (20, 6), (30, 2), (99, 1)], columns=["user_id", "item_id"])
+    assert np.array_equal(m.predict(pairs), r.predict(pairs), equal_nan=True)
+    a, b = m.recommend(VALID_USERS, n_items=3, filter_previous=True), r.recommend(VALID_USERS, n_items=3, filter_previous=True)
+    assert a.equals(b)
+    assert np.array_equal(m.similar_items(1, 3), r.similar_items(1, 3))
+    for k in WEIGHTS:
+        assert np.array_equal(getattr(m, k), getattr(r, k))
+    r.fit_partial(INTX, UF, IF, epochs=1)
+    assert r.epochs_trained == m.epochs_trained + 1 and not np.array_equal(r.v_u, m.v_u)
 
 
 def _golden_frames(g):

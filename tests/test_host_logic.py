@@ -209,3 +209,26 @@ def test_user_items_csr_from_pairs_keeps_duplicates_and_sorts_within_user(monkey
     assert np.array_equal(slow.items, want_items) and np.array_equal(slow.offsets, want_off)
     empty = UserItemsCSR.from_pairs(np.zeros(0, np.int64), np.zeros(0, np.int64), 4)
     assert empty.offsets.tolist() == [0, 0, 0, 0, 0] and len(empty.items) == 0
+
+
+@pytest.mark.parametrize("case", ["bpr_feat_then_none", "warp_feat_then_feat"])
+def test_fit_partial_host_products_match_the_reference(case):
+    """what a resumed fit hands to `_fit` (rankfm/rankfm.py:140-212, 269-327), against the reference's own products
+    (tests/golden/partial_*.npz, make_golden.py partial_case): the new batch's index pairs, the per-user item sets extended --
+    not replaced -- by the batch, and x_uf / x_if rebuilt as zeros when the second call omits the features"""
+    z = load_golden("partial", case)
+    fa = pd.DataFrame({"user_id": z["a_users"], "item_id": z["a_items"]})
+    fb = pd.DataFrame({"user_id": z["b_users"], "item_id": z["b_items"]})
+    uf = pd.concat([pd.DataFrame({"user_id": z["user_id"]}), pd.DataFrame(z["uf_vals"])], axis=1)
+    itf = pd.concat([pd.DataFrame({"item_id": z["item_id"]}), pd.DataFrame(z["if_vals"])], axis=1)
+    m = RankFM(factors=int(z["factors"]), loss=str(z["loss"]), max_samples=int(z["max_samples"]), learning_schedule="invscaling", sigma=0.5)
+    np.random.seed(31)
+    m._init_all(fa, uf, itf)
+    m.is_fit = True                                           # (the device step itself is tested in tests/test_gpu_api.py)
+    with_feat = bool(int(z["second_with_features"]))
+    m._init_interactions(fb, z["b_sw"])
+    m._init_features(uf if with_feat else None, itf if with_feat else None)
+    assert np.array_equal(m.interactions, z["interactions_after"])
+    assert np.array_equal(m.user_items.offsets, z["csr_off_after"]) and np.array_equal(m.user_items.items, z["csr_items_after"])
+    assert np.array_equal(m.x_uf, z["x_uf_after"]) and np.array_equal(m.x_if, z["x_if_after"])
+    assert np.array_equal(m.sample_weight, z["b_sw"])
