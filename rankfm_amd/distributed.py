@@ -122,17 +122,34 @@ class ShardedTrainer:
         self.shared, self.epoch_fn, self.group, self.average = shared, epoch_fn, group, average
         self.syncs_per_epoch = syncs_per_epoch
 
+    def _local(self, epoch, **kw):
+        """one local slice, then agree on its outcome BEFORE the next collective: a rank whose slice failed (saturated user,
+        non-finite weights, a HIP error) would otherwise leave its peers waiting in the all-reduce forever"""
+        err, out = None, None
+        try:
+            out = self.epoch_fn(self.shared.views, epoch, **kw)
+        except Exception as e:      # noqa: BLE001 -- re-raised below, on every rank
+            err = e
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            flag = torch.tensor([0.0 if err is None else 1.0], device=self.shared.flat.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if err is None and flag.item() > 0:
+                err = RuntimeError("another rank's local epoch failed; stopping on every rank")
+        if err is not None:
+            raise err
+        return out
+
     def run_epoch(self, epoch):
         # one epoch = `syncs_per_epoch` slices of the visiting order, each followed by the delta exchange
         if self.syncs_per_epoch <= 1:
             self.shared.begin_epoch()
-            out = self.epoch_fn(self.shared.views, epoch)
+            out = self._local(epoch)
             self.shared.all_reduce_deltas(self.group, self.average)
             return out
         total = None
         for k in range(self.syncs_per_epoch):
             self.shared.begin_epoch()
-            out = self.epoch_fn(self.shared.views, epoch, part=(k, self.syncs_per_epoch))
+            out = self._local(epoch, part=(k, self.syncs_per_epoch))
             self.shared.all_reduce_deltas(self.group, self.average)
             if total is None:
                 total = {key: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for key, v in out.items()}
@@ -155,6 +172,12 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
         # the damping counts updates per exchange window
         shared.set_merge_damping(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), merge_damping)
+    if len(shard["csr_offsets"]) <= 1 or len(shard["interactions"]) == 0:
+        # a rank without users (more ranks than users, or a few heavy users): it trains nothing but still joins every collective
+        def idle_epoch(_views, epoch, part=None):
+            return dict(status=0, log_likelihood=np.zeros(1), reg_penalty=np.zeros(1), sgd_kernel_ms=np.zeros(1, np.float32),
+                        n_draws=np.zeros(1, np.int64), epochs_done=1, launches_per_epoch=0, waves_per_launch=0)
+        return ShardedTrainer(shared, idle_epoch, group=group, average=average, syncs_per_epoch=syncs_per_epoch), None
     weights = dict(shared.views)
     weights["v_u"] = torch.as_tensor(shard["v_u"]).to(device)
     sess = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"],
@@ -203,7 +226,7 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
         trainer, sess = make_device_trainer(shard, tables, model.x_if, hyper, device, group=group, merge_damping=merge_damping,
                                             syncs_per_epoch=syncs_per_epoch, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
                                             want_penalty=verbose, hogwild_damping=model.engine.damping)
-        finish = lambda: sess.weights["v_u"].detach().cpu().numpy()          # noqa: E731
+        finish = (lambda: sess.weights["v_u"].detach().cpu().numpy()) if sess is not None else (lambda: np.zeros((0, model.factors), np.float32))   # noqa: E731
     else:
         trainer, finish = make_trainer(shard, tables, model.x_if, hyper, device, group)
     broadcast_from_rank0([trainer.shared.flat], group)
@@ -222,10 +245,19 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
         getattr(model, k)[...] = trainer.shared.views[k].detach().cpu().numpy()
     v_u_local = np.ascontiguousarray(finish(), dtype=np.float32)
     if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, (lo, hi, v_u_local), group=group)
-        for plo, phi, part in parts:
-            model.v_u[plo:phi] = part
+        # tensors, not pickled objects: every rank contributes its shard padded to the largest shard (2.56 GB of user factors at
+        # BASELINE config 5 would not survive all_gather_object)
+        dev = trainer.shared.flat.device
+        rows = int(np.max(np.diff(bounds)))
+        mine = torch.zeros((max(rows, 1), model.v_u.shape[1]), dtype=torch.float32, device=dev)
+        if hi > lo:
+            mine[:hi - lo] = torch.as_tensor(v_u_local).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        for r in range(world):
+            plo, phi = int(bounds[r]), int(bounds[r + 1])
+            if phi > plo:
+                model.v_u[plo:phi] = parts[r][:phi - plo].cpu().numpy()
     else:
         model.v_u[lo:hi] = v_u_local
     assert np.isfinite(model.v_u).all() and np.isfinite(model.v_i).all(), "model weights are not finite"

@@ -181,3 +181,73 @@ def test_fit_distributed_returns_the_full_model_on_every_rank(tmp_path):
     init_v_u = np.random.normal(0, 0.1, (U, F)).astype(np.float32)
     moved = np.abs(a["v_u"] - init_v_u).max(axis=1)
     assert (moved > 0).all()
+
+
+def _failing_worker(rank, world, port, out_dir):
+    """rank 1's local epoch raises; rank 0's is fine: both must come back with an exception instead of hanging in the all-reduce"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, _, _, w = _problem()
+    shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+
+    def fn(views, epoch):
+        if rank == 1:
+            raise AssertionError("item factors [v_i] are not finite")
+        return dict(ll=np.zeros(1))
+    trainer = ShardedTrainer(shared, fn)
+    try:
+        trainer.run_epoch(0)
+        outcome = "no error"
+    except AssertionError as e:
+        outcome = "own: %s" % e
+    except RuntimeError as e:
+        outcome = "peer: %s" % e
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write(outcome)
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_stops_every_rank_instead_of_hanging_the_job(tmp_path):
+    mp.spawn(_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (tmp_path / "rank0.txt").read_text(), (tmp_path / "rank1.txt").read_text()
+    assert r1.startswith("own: item factors") and r0.startswith("peer: another rank"), (r0, r1)
+
+
+def test_more_ranks_than_users_leaves_idle_ranks_in_the_collectives():
+    """shard_boundaries may hand a rank an empty user range; such a rank builds an idle trainer (no device session) that still
+    takes part in every exchange"""
+    from rankfm_amd.distributed import make_device_trainer
+    off = np.array([0, 5, 9], dtype=np.int64)                    # two users, four ranks
+    b = shard_boundaries(off, 4)
+    assert b[0] == 0 and b[-1] == 2 and np.any(np.diff(b) == 0)
+    _, _, _, w = _problem()
+    empty = dict(interactions=np.zeros((0, 2), np.int32), sample_weight=np.zeros(0, np.float32), csr_offsets=np.zeros(1, np.int64),
+                 csr_items=np.zeros(0, np.int32), x_uf=np.zeros((0, 1), np.float32), v_u=np.zeros((0, F), np.float32))
+    trainer, sess = make_device_trainer(empty, {k: w[k] for k in SHARED_NAMES}, np.zeros((I, 1), np.float32), {}, torch.device("cpu"))
+    assert sess is None
+    before = trainer.shared.flat.clone()
+    out = trainer.run_epoch(0)                                   # no process group: the exchange is a no-op, the epoch is empty
+    assert out["n_draws"][0] == 0 and torch.equal(trainer.shared.flat, before)
+
+
+def test_config_shards_are_the_interaction_balanced_user_split(monkeypatch):
+    """bench.py --config C4 / C5 trains, on rank r of W, synthetic.make_config_shard(name, r, W): the blocks
+    [64 r / W, 64 (r + 1) / W) of ONE data set.  Every block holds the same number of interactions, so that is exactly the split
+    distributed.shard_boundaries makes of the whole data set -- checked at 8 ranks on a scaled-down config 4."""
+    small = dict(n_users=6400, n_items=900, n_interactions=128_000, factors=8, loss="bpr", max_samples=1,
+                 n_user_features=4, n_item_features=4, learning_rate=0.03)
+    monkeypatch.setitem(synthetic.CONFIGS, "C4", small)
+    whole = synthetic.make_config_shard("C4", 0, 1)
+    assert len(whole["interactions"]) == small["n_interactions"] and whole["user_hi"] == small["n_users"]
+    bounds = shard_boundaries(whole["csr_offsets"], 8)
+    assert np.array_equal(bounds, np.arange(9) * (small["n_users"] // 8))
+    for r in (0, 3, 7):
+        sh = synthetic.make_config_shard("C4", r, 8)
+        assert (sh["user_lo"], sh["user_hi"]) == (bounds[r], bounds[r + 1])
+        part = take_user_shard(whole["interactions"], whole["sample_weight"], whole["csr_offsets"], whole["csr_items"], whole["x_uf"],
+                               whole["weights"]["v_u"], bounds[r], bounds[r + 1])
+        assert np.array_equal(np.sort(part["interactions"].view("i8").ravel()), np.sort(sh["interactions"].view("i8").ravel()))
+        assert np.array_equal(part["csr_items"], sh["csr_items"]) and np.array_equal(part["x_uf"], sh["x_uf"])
+        assert np.array_equal(part["v_u"], sh["weights"]["v_u"]) and np.array_equal(sh["x_if"], whole["x_if"])
+        assert all(np.array_equal(sh["weights"][k], whole["weights"][k]) for k in SHARED_NAMES)

@@ -53,3 +53,39 @@ def test_fit_distributed_two_ranks_one_gpu(tmp_path, oracle):
     for k in ("v_u", "v_i", "w_i"):
         got, want = np.linalg.norm(a[k]), np.linalg.norm(getattr(m, k))
         assert abs(got - want) <= 0.05 * want, (k, got, want)
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from rankfm_amd import EngineOptions, RankFM, synthetic
+    from rankfm_amd.distributed import fit_distributed
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # "nccl" IS RCCL on ROCm
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == world
+    pairs, _ = synthetic.make_interactions(U, I, N, seed=1)
+    m = RankFM(factors=F, engine=EngineOptions(seed=9))
+    np.random.seed(4)
+    fit_distributed(m, pairs, epochs=2, device=dev)
+    np.savez(os.path.join(out_dir, "n%d.npz" % rank), v_u=m.v_u, v_i=m.v_i, w_i=m.w_i)
+    dist.destroy_process_group()
+
+
+def test_fit_distributed_over_rccl():
+    """the same fit over the production backend: one rank per visible GPU (two when the box has them, else a world of one) with
+    torch.distributed's "nccl" backend, which is RCCL on ROCm.  With two ranks the replicas must agree bit for bit."""
+    import tempfile
+    import torch
+    world = 2 if torch.cuda.device_count() >= 2 else 1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_nccl_worker, args=(world, port, d), nprocs=world, join=True)
+        r = [np.load(os.path.join(d, "n%d.npz" % k)) for k in range(world)]
+    for k in ("v_u", "v_i", "w_i"):
+        assert np.isfinite(r[0][k]).all() and all(np.array_equal(r[0][k], x[k]) for x in r[1:]), k
