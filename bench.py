@@ -227,7 +227,7 @@ def main():
                        "mean_draws_per_update": mean_draws, "final_mean_ll_per_update": ll_last / N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rfm::sgd_segments_kernel", "kernel_ms_per_launch": k_ms,
+                         "kernel": "rfm::sgd_features_kernel" if (n_uf or n_if) else "rfm::sgd_segments_kernel", "kernel_ms_per_launch": k_ms,
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -783,18 +783,27 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         {h->perms, (void **)&d.perms, h->perms ? sizeof(int32_t) * (size_t)N * cfg->epochs : 0, false},
         {nullptr, &d.workspace, ws_bytes, false},
     };
-    std::vector<void *> allocated;
-    auto cleanup = [&]() { for (void *p : allocated) (void)hipFree(p); };
+    // ONE device allocation for everything (14 hipMalloc / hipFree pairs cost more than a millisecond of a 2.6 ms epoch), carved
+    // on 256-byte boundaries; uploads are enqueued back to back on one stream
+    size_t total = 0;
+    for (Item &it : items) total += align_up(it.bytes ? it.bytes : 16);
+    char *arena = nullptr;
+    {
+        hipError_t e = hipMalloc((void **)&arena, total);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    }
+    auto cleanup = [&]() { (void)hipFree(arena); };
+    hipStream_t stream = nullptr;
+    size_t at = 0;
     for (Item &it : items) {
-        if (it.bytes == 0 && it.dst != (void **)&d.csr_items && it.dst != (void **)&d.interactions &&
-            it.dst != (void **)&d.sample_weight) { *it.dst = nullptr; continue; }
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, it.bytes ? it.bytes : 16);
-        if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMalloc"); }
-        allocated.push_back(p);
+        const bool keep_null = it.bytes == 0 && it.dst != (void **)&d.csr_items && it.dst != (void **)&d.interactions &&
+                               it.dst != (void **)&d.sample_weight;
+        void *p = arena + at;
+        at += align_up(it.bytes ? it.bytes : 16);
+        if (keep_null) { *it.dst = nullptr; continue; }
         *it.dst = p;
         if (it.src && it.bytes) {
-            e = hipMemcpy(p, it.src, it.bytes, hipMemcpyHostToDevice);
+            hipError_t e = hipMemcpyAsync(p, it.src, it.bytes, hipMemcpyHostToDevice, stream);
             if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy H2D"); }
         }
     }
@@ -804,9 +813,11 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
     if (rc == RFM_OK || rc >= RFM_ERR_NONFINITE) {
         for (Item &it : items) {
             if (!it.out) continue;
-            hipError_t e = hipMemcpy(const_cast<void *>(it.src), *it.dst, it.bytes, hipMemcpyDeviceToHost);
+            hipError_t e = hipMemcpyAsync(const_cast<void *>(it.src), *it.dst, it.bytes, hipMemcpyDeviceToHost, stream);
             if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy D2H"); }
         }
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipStreamSynchronize"); }
     }
     cleanup();
     return rc;

