@@ -44,6 +44,9 @@ class EngineOptions:
     rows_per_launch: int = 0
     check_finite: bool = True
     damping: float = 0.0          # hogwild step damping M (include/rankfm_hip.h: hogwild_damping); 0 default, < 0 off
+    negative_stripes: bool = True  # BPR launches of >= 32 workgroups draw each window's negatives from an LDS-held stripe of items
+                                   # and publish their updates once per window: ~25 % faster, measured cost
+                                   # ~0.6 point of hit_rate@10 at 30,000 x 12,000; False = whole-catalogue draws (debug_flags bit 3)
     debug_flags: int = 0          # include/rankfm_hip.h: bit 0 = Hogwild kernel on one row group, bit 1 = L1-bypassing loads
 
     def validated(self):
@@ -204,7 +207,7 @@ def _fit(interactions, sample_weight, user_items, x_uf, x_if, w_i, w_if, v_u, v_
         rng=_hip.RNG_MT19937 if opt.rng == "mt19937" else _hip.RNG_COUNTER, seed=seed & 0xFFFFFFFF,
         check_finite=int(opt.check_finite), want_penalty=int(bool(verbose) or report is not None),
         n_workgroups=int(opt.n_workgroups), rows_per_launch=int(opt.rows_per_launch),
-        hogwild_damping=float(opt.damping), debug_flags=int(opt.debug_flags))
+        hogwild_damping=float(opt.damping), debug_flags=int(opt.debug_flags) | (0 if opt.negative_stripes else 8))
     buf = _hip.FitBuffers(
         interactions=_ptr(interactions), sample_weight=_ptr(sample_weight),
         csr_offsets=_ptr(csr.offsets), csr_items=_ptr(csr.items), x_uf=_ptr(x_uf), x_if=_ptr(x_if),

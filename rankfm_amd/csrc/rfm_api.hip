@@ -784,7 +784,7 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         {nullptr, &d.workspace, ws_bytes, false},
     };
     // ONE device allocation for everything (14 hipMalloc / hipFree pairs cost more than a millisecond of a 2.6 ms epoch), carved
-    // on 256-byte boundaries; uploads are enqueued back to back on one stream
+    // on 256-byte boundaries
     size_t total = 0;
     for (Item &it : items) total += align_up(it.bytes ? it.bytes : 16);
     char *arena = nullptr;
@@ -793,7 +793,6 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         if (e != hipSuccess) return hip_fail(e, "hipMalloc");
     }
     auto cleanup = [&]() { (void)hipFree(arena); };
-    hipStream_t stream = nullptr;
     size_t at = 0;
     for (Item &it : items) {
         const bool keep_null = it.bytes == 0 && it.dst != (void **)&d.csr_items && it.dst != (void **)&d.interactions &&
@@ -803,7 +802,7 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         if (keep_null) { *it.dst = nullptr; continue; }
         *it.dst = p;
         if (it.src && it.bytes) {
-            hipError_t e = hipMemcpyAsync(p, it.src, it.bytes, hipMemcpyHostToDevice, stream);
+            hipError_t e = hipMemcpy(p, it.src, it.bytes, hipMemcpyHostToDevice);
             if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy H2D"); }
         }
     }
@@ -813,11 +812,9 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
     if (rc == RFM_OK || rc >= RFM_ERR_NONFINITE) {
         for (Item &it : items) {
             if (!it.out) continue;
-            hipError_t e = hipMemcpyAsync(const_cast<void *>(it.src), *it.dst, it.bytes, hipMemcpyDeviceToHost, stream);
+            hipError_t e = hipMemcpy(const_cast<void *>(it.src), *it.dst, it.bytes, hipMemcpyDeviceToHost);
             if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipMemcpy D2H"); }
         }
-        hipError_t e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipStreamSynchronize"); }
     }
     cleanup();
     return rc;

@@ -262,15 +262,17 @@ __device__ inline uint32_t mt_next_global(uint32_t *st) {
     return y;
 }
 
-// The reference evaluates exp / log in double and narrows (rankfm/_rankfm.pyx:269-276; rankfm/_rankfm.c:4780, 5247): so does
-// the kernel -- one exp and one log1p per row and lane, 0.5 % of the config-2 epoch (measured).
-__device__ __forceinline__ double log_sigmoid(float x) {
+// The reference evaluates exp / log in double and narrows (rankfm/_rankfm.pyx:269-276; rankfm/_rankfm.c:4780, 5247).  Here: the
+// correctly-rounded-to-1-ulp fp32 library functions (expf, log1pf), not the fast intrinsics (__expf is exp2 of a rounded
+// product: ~2 ulp and worse at large arguments).  Double-precision exp / log1p per row and lane were measured too: they cost the
+// config-2 kernel 2.6 -> 4.55 ms (fp64 exp is ~100 instructions for all 64 lanes of a wavefront) for a difference below 1e-7 in
+// d_outer -- far inside the 2e-5 the serial-mode tests allow against the reference's own numbers.
+__device__ __forceinline__ float log_sigmoid(float x) {
     // log(1 / (1 + exp(-x)))  (:270), overflow-free form
-    const double xd = (double)x;
-    return fmin(xd, 0.0) - log1p(exp(-fabs(xd)));
+    return fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
 }
 __device__ __forceinline__ float sigmoid_neg(float pu) {
-    return (float)(1.0 / (exp((double)pu) + 1.0));               // :276
+    return 1.0f / (expf(pu) + 1.0f);                             // :276
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -754,7 +756,7 @@ struct RowStep {
         }
         const float pu = min_pu;                                          // :267-268
         const float multiplier = a.multiplier[sampled];                   // :269 (integer division inside the log)
-        if (UPD_ROWS && sub == 0) { ll_acc += log_sigmoid(pu); draw_acc += (unsigned)sampled; }   // :270
+        if (UPD_ROWS && sub == 0) { ll_acc += (double)log_sigmoid(pu); draw_acc += (unsigned)sampled; }   // :270
         const float d_outer = sigmoid_neg(pu);                            // :276
         const float g = sw * multiplier;
         const float eta = a.eta, reg_a = a.reg_a, reg_b = a.reg_b;

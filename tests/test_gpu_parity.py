@@ -172,7 +172,9 @@ def test_hogwild_features_statistical_parity(oracle):
     (DESIGN.md section 5.3).  On this problem the tags are random, i.e. the tables hold mostly gradient noise with a memory of
     ~1/(2*beta*eta) = 50 rows: their values are not comparable run to run (two seeds of the reference itself differ), only
     their scale is.  What must track the sequential oracle is the MODEL: per-epoch log-likelihood within 2 %, predicted
-    utilities of random (user, item) pairs correlated > 0.97 with the oracle model's.  The fit is split between item biases,
+    utilities of random (user, item) pairs correlated > 0.93 with the oracle model's (measured 0.957 ... 0.975 over runs; two
+    runs of the sequential oracle itself with different order / draw seeds correlate 0.92 on this problem: the noise in the
+    tables enters every utility).  The fit is split between item biases,
     factors and tables a little differently (8 active tags x the mean table row acts as a bias the item biases can carry
     instead), so the factor norms agree less tightly than without features: measured v_u -5.5 %, v_i -11 %, w_i +8.5 % here
     (bounds 8 / 13 / 12 %), and within 0.2 % once both sides start an epoch from the same weights (test_gpu_configs.py)."""
@@ -188,7 +190,7 @@ def test_hogwild_features_statistical_parity(oracle):
     sg = oracle.predict(pairs, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"])
     so = oracle.predict(pairs, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"])
     c = np.corrcoef(sg, so)[0, 1]
-    assert c > 0.97, "correlation of predicted utilities with the oracle model's %.4f" % c
+    assert c > 0.93, "correlation of predicted utilities with the oracle model's %.4f" % c
     for k in ("v_uf", "v_if", "w_if"):
         assert np.isfinite(g[k]).all()
         assert 0.33 < np.linalg.norm(g[k]) / np.linalg.norm(o[k]) < 3.0, k
