@@ -13,4 +13,5 @@ for k in 1 2 3 4 5 6 7 8; do python bench.py --steps 20 --warmup 3 --no-cpu-base
 python bench.py > gpurun_out/r02_c2_bench.json 2> /dev/null
 python tools/host_path_timing.py > gpurun_out/r02_host_path.log 2>&1
 python tools/movielens_quality.py 3 > gpurun_out/r02_movielens_quality.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r02_smoke.log 2>&1; tail -n 2 gpurun_out/r02_smoke.log
 cat gpurun_out/r02_c2_repeat.log; tail -n 3 gpurun_out/r02_host_path.log; tail -n 8 gpurun_out/r02_movielens_quality.log
