@@ -21,8 +21,11 @@ Everything here works on CPU tensors with the gloo backend as well, which is how
 without GPUs (tests/test_distributed_cpu.py).
 """
 import numpy as np
+import pandas as pd
 import torch
 import torch.distributed as dist
+
+from ._rankfm import UserItemsCSR
 
 SHARED_NAMES = ("v_i", "w_i", "v_if", "w_if", "v_uf")     # replicated tables, in flat-buffer order
 
@@ -197,10 +200,10 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
     the SAME arguments and the same numpy seed.
 
-    Every rank indexes the full data set (cheap, vectorised, identical on all ranks because numpy's RNG state is), takes the
-    user shard of its rank, trains it on its GPU and exchanges the item-side deltas once per epoch (ShardedTrainer).  At the
-    end the user factors are all-gathered, so every rank returns the complete fitted model with the reference's attribute
-    layout.  With world size 1 this is `model.fit(...)` on the resident-session path.
+    Every rank maps the identifiers of the full data set (cheap, vectorised, identical on all ranks because numpy's RNG state
+    is), builds the sorted item lists of ITS users only, trains its user shard on its GPU and exchanges the item-side deltas
+    once per epoch (ShardedTrainer).  At the end the user factors and the item lists are all-gathered, so every rank returns the
+    complete fitted model with the reference's attribute layout.  With world size 1 this is `model.fit(...)` on the resident-session path.
 
     `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
     CPU tests; `finish()` must return the shard's trained v_u as a numpy array.
@@ -210,12 +213,29 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     model._reset_state()
-    model._init_all(interactions, user_features, item_features, sample_weight)
+    # Rank-local indexing: the identifier maps and the index pairs are global (cheap, vectorised, identical on every rank), but
+    # the per-user sorted item lists -- the one O(N log N) step of the front end -- are built by every rank for ITS users only and
+    # exchanged at the end.  The weights are drawn in full on every rank (numpy's stream must advance identically).
+    assert isinstance(interactions, (np.ndarray, pd.DataFrame)), "[interactions] must be np.ndarray or pd.dataframe"
+    assert interactions.shape[1] == 2, "[interactions] should be: [user_id, item_id]"
+    model._init_ids(interactions)
+    pairs = model._index_pairs(interactions, sample_weight)
+    model.interactions = np.ascontiguousarray(pairs, dtype=np.int32)
+    n_users = len(model.user_idx)
+    offsets = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(np.bincount(pairs[:, 0], minlength=n_users), out=offsets[1:])
+    model._init_features(user_features, item_features)
+    model._init_weights(user_features, item_features)
     max_samples = 1 if model.loss == "bpr" else model.max_samples            # rankfm/rankfm.py:294-297
-    bounds = shard_boundaries(model.user_items.offsets, world)
+    bounds = shard_boundaries(offsets, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    shard = take_user_shard(model.interactions, model.sample_weight, model.user_items.offsets, model.user_items.items, model.x_uf,
-                            model.v_u, lo, hi)
+    sel = (pairs[:, 0] >= lo) & (pairs[:, 0] < hi)
+    local = pairs[sel].astype(np.int32, copy=True)
+    local[:, 0] -= lo
+    local_csr = UserItemsCSR.from_pairs(local[:, 0], local[:, 1], hi - lo)
+    shard = dict(interactions=np.ascontiguousarray(local), sample_weight=np.ascontiguousarray(model.sample_weight[sel]),
+                 csr_offsets=local_csr.offsets, csr_items=local_csr.items, x_uf=np.ascontiguousarray(model.x_uf[lo:hi]),
+                 v_u=np.ascontiguousarray(model.v_u[lo:hi]), row_mask=sel)
     hyper = dict(alpha=model.alpha, beta=model.beta, learning_rate=model.learning_rate, learning_schedule=model.learning_schedule,
                  learning_exponent=model.learning_exponent, max_samples=max_samples)
     tables = {k: getattr(model, k) for k in SHARED_NAMES}
@@ -260,6 +280,18 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
                 model.v_u[plo:phi] = parts[r][:phi - plo].cpu().numpy()
     else:
         model.v_u[lo:hi] = v_u_local
+    # the complete per-user item lists on every rank: each rank contributes its users' sorted lists (padded to the longest)
+    if world > 1:
+        dev = trainer.shared.flat.device
+        longest = int(np.max(offsets[bounds[1:]] - offsets[bounds[:-1]]))
+        mine = torch.zeros(max(longest, 1), dtype=torch.int32, device=dev)
+        mine[:len(local_csr.items)] = torch.as_tensor(local_csr.items).to(dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        items = np.concatenate([parts[r][:int(offsets[bounds[r + 1]] - offsets[bounds[r]])].cpu().numpy() for r in range(world)])
+    else:
+        items = local_csr.items
+    model.user_items = UserItemsCSR(offsets, items)
     assert np.isfinite(model.v_u).all() and np.isfinite(model.v_i).all(), "model weights are not finite"
     model.epochs_trained += epochs
     model.is_fit = True

@@ -78,8 +78,15 @@ class RankFM():
         assert isinstance(interactions, (np.ndarray, pd.DataFrame)), "[interactions] must be np.ndarray or pd.dataframe"
         assert interactions.shape[1] == 2, "[interactions] should be: [user_id, item_id]"
 
+        self._init_ids(interactions)
+        self._init_interactions(interactions, sample_weight)
+        self._init_features(user_features, item_features)
+        self._init_weights(user_features, item_features)
+
+    def _init_ids(self, interactions):
+        """the identifier <-> index maps: sorted unique identifiers, zero-based index = rank of the identifier
+        (rankfm/rankfm.py:113-127)"""
         data = get_data(interactions)
-        # sorted unique identifiers; zero-based index = rank of the identifier
         self.user_id = pd.Series(np.sort(pd.unique(data[:, 0])))
         self.item_id = pd.Series(np.sort(pd.unique(data[:, 1])))
         self.index_to_user = self.user_id
@@ -89,20 +96,13 @@ class RankFM():
         self.user_idx = np.arange(len(self.user_id), dtype=np.int32)
         self.item_idx = np.arange(len(self.item_id), dtype=np.int32)
 
-        self._init_interactions(interactions, sample_weight)
-        self._init_features(user_features, item_features)
-        self._init_weights(user_features, item_features)
-
     def _lookup(self, values, which):
         """identifier -> index, -1 where unknown (vectorised counterpart of Series.map(user_to_index))"""
         index = pd.Index(self.index_to_user.values if which == 'user' else self.index_to_item.values)
         return index.get_indexer(pd.Index(values))
 
-    def _init_interactions(self, interactions, sample_weight):
-        """map new interaction data to existing internal user/item indexes (rankfm/rankfm.py:140-177)"""
-        assert isinstance(interactions, (np.ndarray, pd.DataFrame)), "[interactions] must be np.ndarray or pd.dataframe"
-        assert interactions.shape[1] == 2, "[interactions] should be: [user_id, item_id]"
-
+    def _index_pairs(self, interactions, sample_weight):
+        """identifiers -> int32 [N,2] index pairs (and self.sample_weight); no per-user item lists yet"""
         data = get_data(interactions)
         u = self._lookup(data[:, 0], 'user')
         i = self._lookup(data[:, 1], 'item')
@@ -112,7 +112,6 @@ class RankFM():
         pairs = np.empty((len(u), 2), dtype=np.int32)
         pairs[:, 0] = u
         pairs[:, 1] = i
-
         if sample_weight is not None:
             assert isinstance(sample_weight, (np.ndarray, pd.Series)), "[sample_weight] must be np.ndarray or pd.series"
             assert sample_weight.ndim == 1, "[sample_weight] must a vector (ndim=1)"
@@ -120,7 +119,14 @@ class RankFM():
             self.sample_weight = np.ascontiguousarray(get_data(sample_weight), dtype=np.float32)
         else:
             self.sample_weight = np.ones(len(pairs), dtype=np.float32)
+        return pairs
 
+    def _init_interactions(self, interactions, sample_weight):
+        """map new interaction data to existing internal user/item indexes (rankfm/rankfm.py:140-177)"""
+        assert isinstance(interactions, (np.ndarray, pd.DataFrame)), "[interactions] must be np.ndarray or pd.dataframe"
+        assert interactions.shape[1] == 2, "[interactions] should be: [user_id, item_id]"
+
+        pairs = self._index_pairs(interactions, sample_weight)
         n_users = len(self.user_idx)
         if self.is_fit:
             # extend each user's item set with the new observations (set union, so duplicates collapse);

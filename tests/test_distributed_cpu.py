@@ -163,7 +163,8 @@ def _fit_worker(rank, world, port, out_dir):
     m = RankFM(factors=F)
     np.random.seed(3)
     fit_distributed(m, ids, epochs=2, make_trainer=make_trainer)
-    np.savez(os.path.join(out_dir, "fit%d.npz" % rank), v_u=m.v_u, v_i=m.v_i, w_i=m.w_i, users=m.user_id.values.astype("U8"))
+    np.savez(os.path.join(out_dir, "fit%d.npz" % rank), v_u=m.v_u, v_i=m.v_i, w_i=m.w_i, users=m.user_id.values.astype("U8"),
+             csr_off=m.user_items.offsets, csr_items=m.user_items.items, interactions=m.interactions)
     dist.destroy_process_group()
 
 
@@ -181,6 +182,14 @@ def test_fit_distributed_returns_the_full_model_on_every_rank(tmp_path):
     init_v_u = np.random.normal(0, 0.1, (U, F)).astype(np.float32)
     moved = np.abs(a["v_u"] - init_v_u).max(axis=1)
     assert (moved > 0).all()
+    # the per-user item lists were built rank-locally and exchanged: every rank ends with the complete lists the single-process
+    # front end builds
+    from rankfm_amd import UserItemsCSR
+    pairs, _, _, _ = _problem()
+    want = UserItemsCSR.from_pairs(pairs[:, 0], pairs[:, 1], U)
+    for r in (a, b):
+        assert np.array_equal(r["csr_off"], want.offsets) and np.array_equal(r["csr_items"], want.items)
+        assert np.array_equal(r["interactions"], pairs)
 
 
 def _failing_worker(rank, world, port, out_dir):
