@@ -432,8 +432,10 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // statistics of the rank estimate -- against the sequential oracle the log-likelihood moved by -5 % at a 12-row window --
     // and the WARP instantiation gained no time from it (it is bound by its register spills, not by the candidate reads);
     // RFM_WARP_STRIPES=1 switches them on for experiments.
+    // Full factor rows only (n_factors == lanes per group x dwords per lane: 16, 32, 48, 64, 96, 128, ...): the stripe
+    // instantiations carry no per-dword bounds predicate.
     bool use_stripes = use_segments && !feat && !(cfg->debug_flags & 8) && !getenv("RFM_NO_STRIPES") &&
-                       (cfg->max_samples == 1 || getenv("RFM_WARP_STRIPES"));
+                       (cfg->max_samples == 1 || getenv("RFM_WARP_STRIPES")) && cfg->n_factors == shape->group * shape->kpl;
     // ... for launches that fill a good part of the chip: a few workgroups are nowhere near the atomic ceiling (their time is
     // memory latency), and delayed publication only costs them accuracy.  (One group alone keeps the stripes: that is the
     // sequential form of the production kernel the parity tests pin to the oracle.)  The grid is not known yet; estimate it

@@ -421,7 +421,9 @@ struct RowStep {
         : a(args), sub(sub_), F(args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
 
     __device__ __forceinline__ int dword_f(int k) const { return sub + G * k; }
-    __device__ __forceinline__ bool dword_ok(int k) const { return dword_f(k) < F; }
+    // (stripe launches are planned for FULL factor rows only, F == G * KPL: no per-dword predicate -- a v_cmp, an exec-mask
+    //  save and a branch around every load, atomic and LDS update of the row loop otherwise)
+    __device__ __forceinline__ bool dword_ok(int k) const { return STRIPE || dword_f(k) < F; }
 
     template <bool FR>
     __device__ __forceinline__ void load_row(const float *base, float (&r)[KPL]) const {
@@ -1162,7 +1164,7 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
             seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
-                vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                vu0[k] = (STRIPE || sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
                 vu[k] = vu0[k];
             }
             t = 0;
@@ -1202,7 +1204,7 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
                 // one write-back per segment; other segments of a heavy user may be in flight, so add the delta
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
-                    if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                    if (STRIPE || sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
                 have = false;
                 sp += stride;
                 active = sp < a.pos_end;
