@@ -633,11 +633,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.stripe_rows = stripe_rows; a.stripe_window = stripe_window;
         a.item_bits = rfm_perm_bits((uint32_t)cfg->n_items);
         a.launch_index = 0;
-        a.stripe_own = getenv("RFM_STRIPE_OWN") ? atoi(getenv("RFM_STRIPE_OWN")) : 1;   // (experiment knob)
-        a.stripe_bias_direct = getenv("RFM_STRIPE_BIAS") ? atoi(getenv("RFM_STRIPE_BIAS")) : 0;   // (experiment knob)
         a.stripe_cover = stripe_rows > 0 ? std::min(1.0f, (float)grid * (float)stripe_rows / (float)cfg->n_items) : 0.0f;
-        a.stripe_mean = getenv("RFM_STRIPE_MEAN") ? atoi(getenv("RFM_STRIPE_MEAN")) : 1;   // (experiment knob)
-        a.stripe_exact = getenv("RFM_STRIPE_EXACT") ? atoi(getenv("RFM_STRIPE_EXACT")) : 1;   // (experiment knob)
         a.block_threads = waves_per_block * 64;
         // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
         a.eta = cfg->learning_schedule == RFM_SCHEDULE_CONSTANT

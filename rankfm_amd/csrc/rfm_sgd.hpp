@@ -96,11 +96,7 @@ struct SgdArgs {
     // negatives of a window of `stripe_window` rows per group from `stripe_rows` items whose rows it holds in LDS
     int32_t stripe_rows, stripe_window;
     uint32_t item_bits, launch_index;
-    int32_t stripe_own;                         // experiment: 1 = a stripe row's value includes the workgroup's own pending sum
-    int32_t stripe_bias_direct;                 // 1 = the negative's BIAS step is published at once (one atomic), only its factor row waits
     float stripe_cover;                         // share of the catalogue that sits in some workgroup's stripe at any time, <= 1
-    int32_t stripe_mean;                        // 1 = the positive item's view includes the stripe's MEAN pending sum (see RowStep::sn_sum)
-    int32_t stripe_exact;                       // 1 = the stepped negative is re-read from memory (+ own pending sum), 0 = snapshot
 };
 constexpr int kHotBins = 16;
 
@@ -337,7 +333,9 @@ struct RowStep {
     // the membership test of a draw is then four compares and a ballot instead of a memory round trip
     int32_t ulist[4] = {-1, -1, -1, -1};
     bool ulist_ok = false;
+    float user_scale = 1.0f;          // damping of this user's step (SgdArgs::user_cap), constant over a segment
     __device__ __forceinline__ void load_ulist(int64_t lo, int64_t hi) {
+        user_scale = fminf(1.0f, a.user_cap / (float)(hi - lo));
         ulist_ok = (hi - lo) <= 4 * G;
         if (ulist_ok) {
 #pragma unroll
@@ -368,29 +366,22 @@ struct RowStep {
     //       update this way;
     //   published (fresh = true): memory as of now (L1 bypassed) -- everything every workgroup has published, like the view
     //       every step has of its POSITIVE item.  Used for the negative that is actually stepped.
-    // Neither includes the workgroup's own pending sum of the row (SgdArgs::stripe_own = 0): the positive item's pending
-    // pushes sit unseen in some other workgroup's LDS, and a step that saw its negative's pending pushes but not its
-    // positive's would overestimate every pairwise utility (measured: log-likelihood -6 % against the sequential oracle at a
-    // 32-row window, profiles/r02_notes.md).  Seen alike, the two stale views cancel in the pairwise difference.
+    // Both include the workgroup's own pending sum of the row.  The positive item's pending pushes sit unseen in some other
+    // workgroup's LDS, and a step that saw its negative's pending pushes but not its positive's would overestimate every
+    // pairwise utility (measured: log-likelihood -6 % against the sequential oracle at a 32-row window, profiles/r02_notes.md):
+    // the positive's view therefore carries the stripe's MEAN pending sum (sn_sum, operator()).  The alternatives that were
+    // measured (snapshot views, no own sums, biases published at once, reads through the atomic unit) are in the notes; the
+    // kernel compiles the chosen one only.
     __device__ __forceinline__ void fetch_item(int32_t it, int srow, float (&v)[KPL], float &w, bool fresh = true) const {
         if constexpr (STRIPE) {
             if (srow >= 0) {
                 const int base = srow * (F + 1);
-                const float own = a.stripe_own ? kHotUnit : 0.0f;
-                if (!fresh || !a.stripe_exact) {
+                const float own = kHotUnit;
+                if (!fresh) {
 #pragma unroll
                     for (int k = 0; k < KPL; ++k)
                         v[k] = dword_ok(k) ? sn_snap[base + dword_f(k)] + (float)sn_delta[base + dword_f(k)] * own : 0.0f;
                     w = sn_snap[base + F] + (float)sn_delta[base + F] * own;
-                } else if (a.stripe_exact == 2) {     // experiment: read through the memory-side atomic unit
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        v[k] = dword_ok(k) ? __hip_atomic_fetch_add(a.v_i + (size_t)it * F + dword_f(k), 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-                    w = __hip_atomic_fetch_add(a.w_i + (size_t)it * a.w_stride, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        if (dword_ok(k)) v[k] += (float)sn_delta[base + dword_f(k)] * own;
-                    w += (float)sn_delta[base + F] * own;
                 } else {
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) v[k] = dword_ok(k) ? load_f32<true>(a.v_i + (size_t)it * F + dword_f(k)) : 0.0f;
@@ -661,7 +652,7 @@ struct RowStep {
                     wi += (float)hot_accw[slot] * kHotUnit;
                 }
             }
-            if (a.stripe_mean && sn_rows > 0) {
+            if (sn_rows > 0) {
                 const float c = kHotUnit * sn_inv_rows;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
@@ -748,7 +739,7 @@ struct RowStep {
         }
         if constexpr (STRIPE && WARPB) {
             // the negative that was chosen on the snapshot is stepped on its exact view: row, bias and pairwise utility again
-            if (jrow >= 0 && a.stripe_exact) {
+            if (jrow >= 0) {
                 fetch_item(j, jrow, vj, wj, true);
                 float part = 0.0f;
 #pragma unroll
@@ -764,13 +755,16 @@ struct RowStep {
         const float eta = a.eta, reg_a = a.reg_a, reg_b = a.reg_b;
         float eta_u = eta, eta_i = eta, eta_f = eta;
         if constexpr (!SERIAL) {
-            eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
+            if constexpr (STRIPE) eta_u = eta * user_scale;          // (per segment: load_ulist)
+            else eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
             eta_i = eta * pos_scale_i;
             if constexpr (!LDSF) eta_f = eta * a.feat_scale;
         }
-        const bool plain_items = !SERIAL && a.update_mode == 2, plain_user = !SERIAL && (a.update_mode == 1 || a.update_mode == 2);
+        // (experiment knobs of the asynchronous kernels; the stripe instantiations -- the production BPR path -- compile without them)
+        constexpr bool KNOBS = !SERIAL && !STRIPE;
+        const bool plain_items = KNOBS && a.update_mode == 2, plain_user = KNOBS && (a.update_mode == 1 || a.update_mode == 2);
         // experiment (update_mode 3): drop the positive item's atomics when the item is hot -- measures what they cost
-        const bool skip_pos = !SERIAL && ((a.update_mode == 3 && pos_scale_i < 1.0f) || a.update_mode == 4);   // 4: timing experiment
+        const bool skip_pos = KNOBS && ((a.update_mode == 3 && pos_scale_i < 1.0f) || a.update_mode == 4);   // 4: timing experiment
 
         // item biases (:279-280) -- one lane per group
         if (UPD_ROWS && sub == 0) {
@@ -778,9 +772,9 @@ struct RowStep {
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
             if (HOT && slot >= 0) hot_add(hot_accw + slot, dwi);
             else if (!skip_pos) apply_f32<SERIAL>(a.w_i + (size_t)i * a.w_stride, wi, dwi, plain_items);
-            if (STRIPE && jrow >= 0 && !a.stripe_bias_direct) {
+            if (STRIPE && jrow >= 0) {
                 hot_add(sn_delta + jrow * (F + 1) + F, dwj);
-                if (a.stripe_mean) hot_add(sn_sum + F, dwj);
+                hot_add(sn_sum + F, dwj);
             } else apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj, plain_items);
         }
 
@@ -801,7 +795,7 @@ struct RowStep {
                 if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u, plain_user);
                 if (HOT && slot >= 0) hot_add(hot_acc + slot * F + f, d_i);
                 else if (!skip_pos) apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i, plain_items);
-                if (STRIPE && jrow >= 0) { hot_add(sn_delta + jrow * (F + 1) + f, d_j); if (a.stripe_mean) hot_add(sn_sum + f, d_j); }
+                if (STRIPE && jrow >= 0) { hot_add(sn_delta + jrow * (F + 1) + f, d_j); hot_add(sn_sum + f, d_j); }
                 else apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
             }
         }
@@ -1070,7 +1064,7 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
                         if (d != 0) atomic_add_f32(a.v_i + (size_t)it * F + f, (float)d * step.kHotUnit);
                     }
                 }
-                if (sub == 0 && !a.stripe_bias_direct) {
+                if (sub == 0) {
                     const int d = step.sn_delta[base + F];
                     if (d != 0) atomic_add_f32(a.w_i + (size_t)it * a.w_stride, (float)d * step.kHotUnit);
                 }
@@ -1081,12 +1075,12 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
                 for (int k = 0; k < KPL; ++k) {
                     const int f = sub + G * k;
                     if (f < F) {
-                        if (WARPB || !a.stripe_exact) step.sn_snap[base + f] = load_f32<true>(a.v_i + (size_t)it * F + f);   // screening view
+                        if (WARPB) step.sn_snap[base + f] = load_f32<true>(a.v_i + (size_t)it * F + f);   // screening view
                         step.sn_delta[base + f] = 0;
                     }
                 }
                 if (sub == 0) {
-                    if (WARPB || !a.stripe_exact) step.sn_snap[base + F] = load_f32<true>(a.w_i + (size_t)it * a.w_stride);
+                    if (WARPB) step.sn_snap[base + F] = load_f32<true>(a.w_i + (size_t)it * a.w_stride);
                     step.sn_delta[base + F] = 0;
                     step.sn_item[slot] = it;
                 }
