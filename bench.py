@@ -84,7 +84,6 @@ def main():
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--rows-per-launch", type=int, default=0)
     ap.add_argument("--zipf", type=float, default=1.0)
-    ap.add_argument("--update-mode", type=int, default=0, help="experiment: 0 atomics, 1 v_u plain, 2 all plain")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--damping", type=float, default=0.0, help="hogwild damping M (0 default, <0 off)")
     ap.add_argument("--debug-flags", type=int, default=0)
@@ -161,7 +160,7 @@ def main():
     trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
                                         syncs_per_epoch=args.syncs_per_epoch, seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
                                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
-                                        update_mode=args.update_mode, shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check)
+                                        shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check)
     broadcast_from_rank0([trainer.shared.flat])
 
     def barrier():

@@ -98,7 +98,7 @@ typedef struct rfm_fit_config {
     float hogwild_damping;         /* M: a row touched by n in-flight updates at once is stepped with min(1, M/n) of the
                                       learning rate (n = in-flight rows x the row's share of the data).  0 = default (128),
                                       < 0 = off.  Ignored in serial mode. */
-    int32_t debug_update_mode;     /* experiments: 0 all atomics (default), 1 v_u plain stores, 2 everything plain stores */
+    int32_t debug_update_mode;     /* reserved, ignored (the plain-store experiments of rounds 1-2 are gone; profiles/r02_notes.md) */
     int32_t debug_shape;           /* experiments: 1-based index into the kernel shape table, 0 = automatic */
     int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
                                       bit 1: factor-row loads bypass the per-CU L1,

@@ -42,6 +42,11 @@ def _stale(target, sources):
 
 def _compile(src):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    # RFM_BUILD_SHAPES="g16_k4 ..." (kernel development only): recompile just these row-group shapes and the host code and link
+    # the other shapes' existing objects.  Only valid while SgdArgs is unchanged; a normal build recompiles everything stale.
+    only = os.environ.get("RFM_BUILD_SHAPES", "").split()
+    if only and os.path.exists(obj) and "rfm_sgd_inst_" in src and not any(t in src for t in only):
+        return obj
     if _stale(obj, [src] + _deps()):
         subprocess.check_call([_hipcc()] + FLAGS + ["-c", src, "-o", obj])
     return obj

@@ -641,7 +641,6 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
                     : (float)((double)cfg->learning_rate / pow((double)(epoch + 1), (double)cfg->learning_exponent));
         a.reg_a = 2.0f * cfg->alpha;      // :171
         a.reg_b = 2.0f * cfg->beta;       // :172
-        a.update_mode = cfg->debug_update_mode;
         a.pos_scale = damp ? ws.pos_scale : nullptr;
         a.user_cap = damp ? damp_cap / avg_seg : INFINITY;
         // the dense feature tables are touched by EVERY in-flight row and shrink by 2*beta*eta per touch: keep the summed

@@ -71,7 +71,6 @@ struct SgdArgs {
     const float *__restrict__ pos_scale;        // [I] scale for the positive item's row (by item popularity), or nullptr
     float user_cap;                             // a user of degree d gets min(1, user_cap / d)
     float feat_scale;                           // scale for the dense feature tables (every row touches them)
-    int32_t update_mode;                        // experiments: 0 all atomics, 1 v_u plain RMW, 2 everything plain RMW
     int32_t single_group;                       // debug: only group 0 of wavefront 0 works (sequential Hogwild kernel)
     int64_t max_groups;                         // row groups allowed to work (the concurrency cap can be below one workgroup)
     int32_t block_threads;                      // workgroup size of the features kernel
@@ -160,8 +159,8 @@ __device__ __forceinline__ float load_f32(const float *p) {
 }
 
 template <bool PLAIN, class Ptr>
-__device__ __forceinline__ void apply_f32(Ptr p, float oldv, float delta, bool plain_rt = false) {
-    if (PLAIN || plain_rt) *p = oldv + delta;
+__device__ __forceinline__ void apply_f32(Ptr p, float oldv, float delta) {
+    if (PLAIN) *p = oldv + delta;
     else atomic_add_f32(p, delta);
 }
 
@@ -263,12 +262,13 @@ __device__ inline uint32_t mt_next_global(uint32_t *st) {
 // product: ~2 ulp and worse at large arguments).  Double-precision exp / log1p per row and lane were measured too: they cost the
 // config-2 kernel 2.6 -> 4.55 ms (fp64 exp is ~100 instructions for all 64 lanes of a wavefront) for a difference below 1e-7 in
 // d_outer -- far inside the 2e-5 the serial-mode tests allow against the reference's own numbers.
-__device__ __forceinline__ float log_sigmoid(float x) {
-    // log(1 / (1 + exp(-x)))  (:270), overflow-free form
-    return fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
-}
-__device__ __forceinline__ float sigmoid_neg(float pu) {
-    return 1.0f / (expf(pu) + 1.0f);                             // :276
+// log(1 / (1 + exp(-x))) (:270) and 1 / (1 + exp(x)) (:276) from ONE exponential, e = exp(-|x|) in (0, 1]: overflow-free, and
+// the reciprocal of 1 + e in (1, 2] is the hardware's 1-ulp v_rcp_f32 instead of the ten-instruction IEEE division sequence.
+__device__ __forceinline__ void sigmoid_terms(float x, float &log_sig, float &sig_neg) {
+    const float e = expf(-fabsf(x));
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    log_sig = fminf(x, 0.0f) - log1pf(e);
+    sig_neg = x >= 0.0f ? e * r : r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -749,8 +749,9 @@ struct RowStep {
         }
         const float pu = min_pu;                                          // :267-268
         const float multiplier = a.multiplier[sampled];                   // :269 (integer division inside the log)
-        if (UPD_ROWS && sub == 0) { ll_acc += (double)log_sigmoid(pu); draw_acc += (unsigned)sampled; }   // :270
-        const float d_outer = sigmoid_neg(pu);                            // :276
+        float log_sig, d_outer;
+        sigmoid_terms(pu, log_sig, d_outer);                              // :270, :276
+        if (UPD_ROWS && sub == 0) { ll_acc += (double)log_sig; draw_acc += (unsigned)sampled; }
         const float g = sw * multiplier;
         const float eta = a.eta, reg_a = a.reg_a, reg_b = a.reg_b;
         float eta_u = eta, eta_i = eta, eta_f = eta;
@@ -760,22 +761,16 @@ struct RowStep {
             eta_i = eta * pos_scale_i;
             if constexpr (!LDSF) eta_f = eta * a.feat_scale;
         }
-        // (experiment knobs of the asynchronous kernels; the stripe instantiations -- the production BPR path -- compile without them)
-        constexpr bool KNOBS = !SERIAL && !STRIPE;
-        const bool plain_items = KNOBS && a.update_mode == 2, plain_user = KNOBS && (a.update_mode == 1 || a.update_mode == 2);
-        // experiment (update_mode 3): drop the positive item's atomics when the item is hot -- measures what they cost
-        const bool skip_pos = KNOBS && ((a.update_mode == 3 && pos_scale_i < 1.0f) || a.update_mode == 4);   // 4: timing experiment
-
         // item biases (:279-280) -- one lane per group
         if (UPD_ROWS && sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
             if (HOT && slot >= 0) hot_add(hot_accw + slot, dwi);
-            else if (!skip_pos) apply_f32<SERIAL>(a.w_i + (size_t)i * a.w_stride, wi, dwi, plain_items);
+            else apply_f32<SERIAL>(a.w_i + (size_t)i * a.w_stride, wi, dwi);
             if (STRIPE && jrow >= 0) {
                 hot_add(sn_delta + jrow * (F + 1) + F, dwj);
                 hot_add(sn_sum + F, dwj);
-            } else apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj, plain_items);
+            } else apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj);
         }
 
         // factor updates (:289-326), this lane's dwords
@@ -792,11 +787,11 @@ struct RowStep {
             dij[k] = (vi[k] + d_i) - (vj[k] + d_j);
             if (UPD_ROWS && dword_ok(k)) {
                 const int f = dword_f(k);
-                if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u, plain_user);
+                if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u);
                 if (HOT && slot >= 0) hot_add(hot_acc + slot * F + f, d_i);
-                else if (!skip_pos) apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i, plain_items);
+                else apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i);
                 if (STRIPE && jrow >= 0) { hot_add(sn_delta + jrow * (F + 1) + f, d_j); hot_add(sn_sum + f, d_j); }
-                else apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j, plain_items);
+                else apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j);
             }
         }
         if constexpr (VU_REGS && UPD_ROWS) {
@@ -1361,8 +1356,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
     constexpr int kRefreshEvery = 4;                               // rows between table refreshes of a workgroup
     for (int iter = 0; __any(active); ++iter) {
-        const int every = a.update_mode == 6 ? 1 : kRefreshEvery;       // (experiment: refresh every row)
-        if (!a.single_group && a.update_mode != 5 && iter % every == 0 && (iter / every) % n_waves == wave) {
+        if (!a.single_group && iter % kRefreshEvery == 0 && (iter / kRefreshEvery) % n_waves == wave) {
             // this wavefront's turn to bring the workgroup's copy up to date (readers may see a row half old, half new:
             // both are tables the trainer published)
             for (int k = lane; k < n_tab; k += 64)

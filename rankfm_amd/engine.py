@@ -19,7 +19,7 @@ class DeviceSession:
                  learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25, max_samples=1,
                  mode="hogwild", rng="counter", seed=1492, device=None, n_workgroups=0, rows_per_launch=0,
                  check_finite=True, want_penalty=False, has_user_features=None, has_item_features=None,
-                 update_mode=0, shape_override=0, hogwild_damping=0.0, debug_flags=0):
+                 shape_override=0, hogwild_damping=0.0, debug_flags=0):
         if not torch.cuda.is_available():
             raise _hip.EngineUnavailable("no MI355X visible to PyTorch-ROCm: rankfm_amd has no CPU fallback")
         _hip.lib()
@@ -60,7 +60,6 @@ class DeviceSession:
         self.n_workgroups, self.rows_per_launch = int(n_workgroups), int(rows_per_launch)
         self.check_finite, self.want_penalty = int(check_finite), int(want_penalty)
         self._workspace = None
-        self.update_mode = int(update_mode)
         self.shape_override = int(shape_override)
         self.hogwild_damping = float(hogwild_damping)
         self._plan_token = 0
@@ -72,7 +71,7 @@ class DeviceSession:
             rng_epoch_offset=int(rng_epoch_offset),
             epoch_part_index=part[0] if part else 0, epoch_parts=part[1] if part else 0,
             hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token), debug_flags=self.debug_flags,
-            debug_update_mode=self.update_mode, debug_shape=self.shape_override,
+            debug_update_mode=0, debug_shape=self.shape_override,
             n_interactions=self.n_interactions, n_users=self.n_users, n_items=self.n_items,
             n_user_features=self.n_user_features, n_item_features=self.n_item_features, n_factors=self.n_factors,
             has_user_features=self.has_uf, has_item_features=self.has_if,

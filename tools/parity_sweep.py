@@ -30,7 +30,6 @@ ap.add_argument("--sigma", type=float, default=0.1)
 ap.add_argument("--no-oracle", action="store_true")
 ap.add_argument("--debug-flags", default="0")
 ap.add_argument("--lr", type=float, default=0.1)
-ap.add_argument("--update-mode", type=int, default=0)
 ap.add_argument("--env", default="", help="variants of engine environment knobs: 'A=1,B=2;A=3' runs two variants")
 a = ap.parse_args()
 U, I, N, F = a.users, a.items, a.rows, a.factors
@@ -62,7 +61,7 @@ for envs in a.env.split(";"):
     for rpl in [int(x) for x in a.rows_per_launch.split(",")]:
           for m, fl in [(float(x), int(y)) for x in a.dampings.split(",") for y in a.debug_flags.split(",")]:
               sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=a.max_samples, seed=1492, learning_rate=a.lr,
-                                   hogwild_damping=m, n_workgroups=wg, rows_per_launch=rpl, debug_flags=fl, update_mode=a.update_mode)
+                                   hogwild_damping=m, n_workgroups=wg, rows_per_launch=rpl, debug_flags=fl)
               rep = sess.run(epochs=a.epochs, raise_on_error=False)
               g = sess.weights_to_host()
               line = "flags=%d " % fl + "wg=%4d rpl=%8d M=%6.1f st=%d launches=%d ms %s ll/N %s" % (wg, rpl, m, rep["status"], rep["launches_per_epoch"],
