@@ -18,7 +18,9 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "librankfm_hip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function",
+         # LDS / memory atomics of a few lanes on one address are cheaper left to the hardware than turned into a scalar loop
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def _hipcc():

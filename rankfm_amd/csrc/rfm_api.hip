@@ -435,7 +435,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // Full factor rows only (n_factors == lanes per group x dwords per lane: 16, 32, 48, 64, 96, 128, ...): the stripe
     // instantiations carry no per-dword bounds predicate.
     bool use_stripes = use_segments && !feat && !(cfg->debug_flags & 8) && !getenv("RFM_NO_STRIPES") &&
-                       (cfg->max_samples == 1 || getenv("RFM_WARP_STRIPES")) && cfg->n_factors == shape->group * shape->kpl;
+                       (cfg->max_samples == 1 || getenv("RFM_WARP_STRIPES")) && cfg->n_factors == shape->group * shape->kpl &&
+                       (damp || single_group);     // undamped Hogwild on skewed data needs every push published at once (notes)
     // ... for launches that fill a good part of the chip: a few workgroups are nowhere near the atomic ceiling (their time is
     // memory latency), and delayed publication only costs them accuracy.  (One group alone keeps the stripes: that is the
     // sequential form of the production kernel the parity tests pin to the oracle.)  The grid is not known yet; estimate it
@@ -580,7 +581,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // (WARP reads a bias per candidate, ~20 per update: there the 16x larger table costs more in read misses than the
     // atomics gain -- config 3: 318 M updates/s unpadded, 306 M padded -- so only BPR-like sampling pads)
     // (with stripes the candidates' biases are LDS reads, so WARP pads as well)
-    const bool pad_bias = !serial && (use_stripes || cfg->max_samples <= 4) && !getenv("RFM_NO_BIAS_PAD");   // (experiment knob)
+    const bool pad_bias = !serial && (use_stripes || cfg->max_samples <= 4);
     if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, damp ? ws.pos_scale : nullptr, cfg->n_items);
     // timing events: destroyed on every exit path
     struct Events {
@@ -614,7 +615,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         SgdArgs a;
         a.interactions = b->interactions; a.sample_weight = b->sample_weight;
         a.csr_off = b->csr_offsets; a.csr_items = b->csr_items; a.x_uf = b->x_uf; a.x_if = b->x_if;
-        a.w_i = pad_bias ? ws.w_pad : b->w_i; a.w_stride = pad_bias ? kBiasStride : 1; a.scale_in_pad = pad_bias && damp ? 1 : 0; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
+        a.w_i = pad_bias ? ws.w_pad : b->w_i; a.w_stride = pad_bias ? kBiasStride : 1; a.scale_in_pad = pad_bias ? 1 : 0; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
         a.perm = b->perms ? b->perms + (size_t)e * N : nullptr;
         a.multiplier = ws.multiplier; a.mt_state = ws.mt_state;
         a.ll = ws.ll + e; a.draws = ws.draws + e; a.error_flags = ws.error_flags;

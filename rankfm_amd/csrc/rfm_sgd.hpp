@@ -119,6 +119,10 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
 }
+template <int CTRL>
+__device__ __forceinline__ int32_t dpp_movi(int32_t x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
+}
 template <int G>
 __device__ __forceinline__ float group_sum(float x) {
     if constexpr (G >= 16) {
@@ -267,7 +271,10 @@ __device__ inline uint32_t mt_next_global(uint32_t *st) {
 __device__ __forceinline__ void sigmoid_terms(float x, float &log_sig, float &sig_neg) {
     const float e = expf(-fabsf(x));
     const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    log_sig = fminf(x, 0.0f) - log1pf(e);
+    // The log-likelihood is a reported statistic, not part of the update: log(1 + e) through the hardware log2 (absolute error
+    // ~1e-7 per row; the library's log1pf is ~130 instructions of compensated arithmetic that every lane of the wavefront would
+    // execute for the one lane per row that accumulates it -- a fifth of the BPR row loop).
+    log_sig = fminf(x, 0.0f) - __logf(1.0f + e);
     sig_neg = x >= 0.0f ? e * r : r;
 }
 
@@ -549,7 +556,7 @@ struct RowStep {
     struct PosRow { float v[KPL]; float w, scale; };
     __device__ __forceinline__ void prefetch_pos(int32_t it, PosRow &p) const {
         load_row<FRESH>(a.v_i + (size_t)it * F, p.v);
-        if (a.scale_in_pad) {
+        if (STRIPE || a.scale_in_pad) {
             // lanes 0 / 1 of the group read dwords 0 / 1 of the item's line: bias and step scale in ONE request
             const float x = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride + (sub & 1));
             const int base = (threadIdx.x & 63) - sub;
@@ -576,8 +583,9 @@ struct RowStep {
         int slot = -1;
         float pos_scale_i = 1.0f;
         if constexpr (!SERIAL) {
-            if (a.pos_scale) {
-                pos_scale_i = pre ? pre->scale : a.pos_scale[i];
+            if (STRIPE || a.pos_scale) {
+                // (stripe launches always carry bias and step scale in the item's padded line: scale 1 when nothing is damped)
+                pos_scale_i = (STRIPE || pre) ? pre->scale : a.pos_scale[i];
                 if constexpr (HOT) {
                     if (pos_scale_i >= 2.0f) {
                         slot = (int)(pos_scale_i * 0.5f) - 1;
@@ -761,6 +769,53 @@ struct RowStep {
             eta_i = eta * pos_scale_i;
             if constexpr (!LDSF) eta_f = eta * a.feat_scale;
         }
+        float nvu[KPL], dij[KPL];     // updated v_u, updated (v_i - v_j) (feature paths)
+        if constexpr (STRIPE && !SERIAL && !FEAT && VU_REGS) {
+            // The same arithmetic as the generic code below, arranged for the stripe instantiations: every delta first, then ONE
+            // branch per publication target (hot slot or atomics for the positive, stripe row or atomics for the negative)
+            // instead of one per dword.
+            float d_i[KPL], d_j[KPL];
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                const float g_u = vi[k] - vj[k];                                     // :292
+                const float g_i = vu[k];                                             // :293-294 (d_v_j = -d_v_i)
+                const float d_u = eta_u * (g * (d_outer * g_u) - reg_a * vu[k]);     // :308
+                d_i[k] = eta_i * (g * (d_outer * g_i) - reg_a * vi[k]);              // :309
+                d_j[k] = eta * (g * (d_outer * -g_i) - reg_a * vj[k]);               // :310
+                vu[k] += d_u;
+            }
+            const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);           // :279
+            const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);            // :280
+            if (HOT && slot >= 0) {
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) hot_add(hot_acc + slot * F + dword_f(k), d_i[k]);
+                if (sub == 0) hot_add(hot_accw + slot, dwi);
+            } else {
+                float *pv = a.v_i + (size_t)i * F + sub;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) atomic_add_f32(pv + G * k, d_i[k]);
+                if (sub == 0) atomic_add_f32(a.w_i + (size_t)i * a.w_stride, dwi);
+            }
+            if (jrow >= 0) {
+                lds_int *pd = sn_delta + jrow * (F + 1) + sub, *ps = sn_sum + sub;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) {
+                    const int q = __float2int_rn(d_j[k] * kHotScale);
+                    __hip_atomic_fetch_add(pd + G * k, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(ps + G * k, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (sub == 0) {
+                    const int q = __float2int_rn(dwj * kHotScale);
+                    __hip_atomic_fetch_add(sn_delta + jrow * (F + 1) + F, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(sn_sum + F, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                float *pv = a.v_i + (size_t)j * F + sub;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) atomic_add_f32(pv + G * k, d_j[k]);
+                if (sub == 0) atomic_add_f32(a.w_i + (size_t)j * a.w_stride, dwj);
+            }
+        } else {
         // item biases (:279-280) -- one lane per group
         if (UPD_ROWS && sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
@@ -774,7 +829,6 @@ struct RowStep {
         }
 
         // factor updates (:289-326), this lane's dwords
-        float nvu[KPL], dij[KPL];     // updated v_u, updated (v_i - v_j)
 #pragma unroll
         for (int k = 0; k < KPL; ++k) {
             float g_u = vi[k] - vj[k];                                    // :292
@@ -798,11 +852,12 @@ struct RowStep {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) vu[k] = nvu[k];
         }
+        }
         if constexpr (HOT) {
             if (slot >= 0) {
                 // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it
                 // (a keyed coin with probability 1 / period instead of a shared counter: no LDS round trip on the row's path)
-                if (rfm_mix32(row_key ^ 0x7A5C3B1DU) % (uint32_t)a.hot_period[slot] == 0u) {
+                if (__umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)a.hot_period[slot]) == 0u) {     // probability 1 / period
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
@@ -1105,18 +1160,36 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
     float seg_sw[SEGR];
     typename Step::PosRow cur_pos, next_pos;
     const int lane_base = lane - sub;
-    // row t of the segment: register t / G of lane t % G (the register index is selected, not indexed: registers stay registers)
-    auto seg_get = [&](const int32_t (&r)[SEGR], int tt) {
+    // row t of the segment: register t / G of lane t % G (the register index is selected, not indexed: registers stay registers).
+    // 16-lane groups are DPP rows: the registers are ROTATED one lane per processed row (seg_rotate), so the current row is
+    // always in lane 0 and the next one in lane 1 of the selected register -- a row_share move, no LDS shuffle and no index math.
+    auto seg_pick = [&](const int32_t (&r)[SEGR], int tt) {
         int32_t x = r[0];
 #pragma unroll
-        for (int k = 1; k < SEGR; ++k) x = (tt / G == k) ? r[k] : x;
-        return __shfl(x, lane_base + tt % G);
+        for (int k = 1; k < SEGR; ++k) x = ((unsigned)tt / G == (unsigned)k) ? r[k] : x;
+        return x;
+    };
+    auto seg_get = [&](const int32_t (&r)[SEGR], int tt, bool next = false) {
+        const int32_t x = seg_pick(r, tt);
+        if constexpr (G == 16 && STRIPE) return next ? dpp_movi<0x151>(x) : dpp_movi<0x150>(x);      // row_share:1 / row_share:0
+        else return __shfl(x, lane_base + (int)((unsigned)tt % G));
     };
     auto seg_getf = [&](const float (&r)[SEGR], int tt) {
         float x = r[0];
 #pragma unroll
-        for (int k = 1; k < SEGR; ++k) x = (tt / G == k) ? r[k] : x;
-        return __shfl(x, lane_base + tt % G);
+        for (int k = 1; k < SEGR; ++k) x = ((unsigned)tt / G == (unsigned)k) ? r[k] : x;
+        if constexpr (G == 16 && STRIPE) return dpp_mov<0x150>(x);
+        else return __shfl(x, lane_base + (int)((unsigned)tt % G));
+    };
+    auto seg_rotate = [&]() {
+        if constexpr (G == 16 && STRIPE) {
+#pragma unroll
+            for (int k = 0; k < SEGR; ++k) {
+                seg_item[k] = dpp_movi<0x12F>(seg_item[k]);       // row_ror:15: lane s takes lane s + 1
+                seg_pos[k] = dpp_movi<0x12F>(seg_pos[k]);
+                seg_sw[k] = dpp_mov<0x12F>(seg_sw[k]);
+            }
+        }
     };
 
     for (int iter = 0;; ++iter) {
@@ -1181,7 +1254,8 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
                 // (one group alone is a sequential program: a repeated (user, item) row must see the previous row's update of
                 // the same item, so nothing is fetched ahead there)
                 if (a.single_group) step.prefetch_pos(i, cur_pos);
-                else if (t + 1 < len) step.prefetch_pos(seg_get(seg_item, t + 1), next_pos);     // overlaps this row
+                else if (t + 1 < len) step.prefetch_pos(seg_get(seg_item, t + 1, true), next_pos);     // overlaps this row
+                seg_rotate();
                 step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc, &cur_pos);
             } else {
                 pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);

@@ -258,13 +258,15 @@ def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
     rep = sess.run(epochs=2)
     g = sess.weights_to_host()
     o, out = _oracle_in_engine_order(oracle, (pairs, csr, sw, x_uf, x_if, None), w, 1, 2, 1492, geometry=sess.geometry())
-    # log-likelihood: 1.8 % in the first epoch (measured +1.2 %: the 64 hottest items are trained through per-workgroup LDS
-    # accumulators and damped accordingly, which costs them a little progress early on), 1.2 % in the second (measured +0.8 %);
-    # norms measured +0.03 % / +0.12 % / +0.7 % (v_u, v_i, w_i)
+    # log-likelihood within BASELINE.json's 2 % in the first epoch and 1.4 % in the second.  Measured (tools/c2_ll_ratio.py,
+    # several builds): +1.72 ... +1.79 % / +1.12 ... +1.16 %, of which +1.1 % / +0.8 % without the negative stripes (the 64
+    # hottest items are trained through per-workgroup LDS accumulators and damped accordingly, which costs them a little
+    # progress early on) and +0.6 % / +0.3 % from the stripes' delayed publication; norms +0.07 % / +0.26 % / +0.4 %
+    # (v_u, v_i, w_i)
     print("full-size config 2: LL gpu/oracle - 1 =", rep["log_likelihood"] / out["ll"] - 1.0, " norms gpu/oracle - 1 =",
           [float(np.linalg.norm(g[k]) / np.linalg.norm(o[k]) - 1.0) for k in ("v_u", "v_i", "w_i")])
-    _assert_statistical_parity(g, rep, o, out, ll_tol=0.018)
-    np.testing.assert_allclose(rep["log_likelihood"][1:], out["ll"][1:], rtol=0.012)
+    _assert_statistical_parity(g, rep, o, out, ll_tol=0.02)
+    np.testing.assert_allclose(rep["log_likelihood"][1:], out["ll"][1:], rtol=0.014)
 
 
 @pytest.mark.parametrize("damping", [-1.0, 1e9])
