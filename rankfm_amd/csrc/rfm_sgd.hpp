@@ -266,15 +266,14 @@ __device__ inline uint32_t mt_next_global(uint32_t *st) {
 // product: ~2 ulp and worse at large arguments).  Double-precision exp / log1p per row and lane were measured too: they cost the
 // config-2 kernel 2.6 -> 4.55 ms (fp64 exp is ~100 instructions for all 64 lanes of a wavefront) for a difference below 1e-7 in
 // d_outer -- far inside the 2e-5 the serial-mode tests allow against the reference's own numbers.
-// log(1 / (1 + exp(-x))) (:270) and 1 / (1 + exp(x)) (:276) from ONE exponential, e = exp(-|x|) in (0, 1]: overflow-free, and
-// the reciprocal of 1 + e in (1, 2] is the hardware's 1-ulp v_rcp_f32 instead of the ten-instruction IEEE division sequence.
+// log(1 / (1 + exp(-x))) (:270) and 1 / (1 + exp(x)) (:276) from ONE exponential, e = exp(-|x|) in (0, 1]: overflow-free, the
+// 1-ulp library functions (expf, log1pf) and an IEEE division.  (The hardware's log2 / reciprocal instead of log1pf / the division
+// were measured on config 2: ~130 fewer instructions per row and under 1 % of the kernel time -- the row loop is not bound by
+// its arithmetic -- so the accurate forms stay.)
 __device__ __forceinline__ void sigmoid_terms(float x, float &log_sig, float &sig_neg) {
     const float e = expf(-fabsf(x));
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    // The log-likelihood is a reported statistic, not part of the update: log(1 + e) through the hardware log2 (absolute error
-    // ~1e-7 per row; the library's log1pf is ~130 instructions of compensated arithmetic that every lane of the wavefront would
-    // execute for the one lane per row that accumulates it -- a fifth of the BPR row loop).
-    log_sig = fminf(x, 0.0f) - __logf(1.0f + e);
+    const float r = 1.0f / (1.0f + e);
+    log_sig = fminf(x, 0.0f) - log1pf(e);
     sig_neg = x >= 0.0f ? e * r : r;
 }
 
