@@ -521,12 +521,16 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         // drifts from the sequential oracle's in proportion to the window (config 2: -0.3 / -2.3 / -5.8 % at 8 / 16 / 32 rows);
         // with BOTH items seen as published (RowStep::fetch_item) the staleness is symmetric and the log-likelihood no longer
         // moves with the window (+1.7 / +1.6 / +1.7 %, +1.2 % without stripes), only the norms creep up (+0.5 -> +0.9 % on v_i)
-        // as several pushes of a window start from the same published value.  Window = 4 I / groups rows (<= 32): ~2 pending
-        // pushes per item; stripe = groups x window / 2 rows (<= 256): ~2-3 pushes per row and publication -- a smaller stripe
-        // would combine more (64 rows: 2.46 instead of 2.63 ms at window 8), but concentrates the pending pushes on fewer
-        // rows, and past that point the atomics no longer bound the kernel.
+        // as several pushes of a window start from the same published value.  With the positive's view corrected by the stripe's
+        // mean pending sum (the committed form, RowStep::sn_sum) the measured log-likelihood against the sequential oracle on
+        // config 2 is, epochs 1 / 2 (tools/c2_ll_ratio.py): 6 rows +2.1 / +1.4 %, 8 rows +1.9 / +1.3 %, 12 rows +1.6 ... +1.8 /
+        // +0.9 ... +1.1 %, 16 rows +1.6 / +0.8 %, 24 rows +1.0 / +0.2 % (|w_i| -0.6 %, |v_i| +0.15 %), +1.1 / +0.8 % without
+        // stripes; kernel 2.45 / 2.25 / 2.15 / 2.12 / 2.0 ms.  Window = 8 I / groups rows (<= 32; 24 on config 2): ~4 pending
+        // pushes per item, where the two opposite biases of delayed publication leave the widest margin to the 2 % bar on both
+        // sides; stripe = groups x window / 2 rows (<= 256): a smaller stripe would combine more pushes per publication but
+        // concentrates the pending pushes on fewer rows, and the atomics no longer bound the kernel.
         const long long g_work = single_group ? 1 : std::min<long long>((long long)grid * gpb, max_groups > 0 ? max_groups : (1LL << 60));
-        stripe_window = (int)std::max<long long>(1, std::min<long long>(32, (long long)(4.0 * (double)cfg->n_items / (double)g_work + 0.5)));
+        stripe_window = (int)std::max<long long>(1, std::min<long long>(32, (long long)(8.0 * (double)cfg->n_items / (double)g_work + 0.5)));
         if (getenv("RFM_STRIPE_WINDOW")) stripe_window = std::max(1, atoi(getenv("RFM_STRIPE_WINDOW")));                     // (experiment knob)
         if (single_group) stripe_window = 1;      // one group alone: a fresh stripe for every row keeps it exactly sequential
         const int combine = getenv("RFM_STRIPE_COMBINE") ? std::max(1, atoi(getenv("RFM_STRIPE_COMBINE"))) : 2;             // (experiment knob)

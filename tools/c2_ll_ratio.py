@@ -1,6 +1,7 @@
 """Config 2 at full size: two epochs on the GPU against the sequential oracle on the same order and draws, for a few engine
 settings (what each mechanism of the production kernel costs in log-likelihood / norms).  Test infrastructure (uses oracle/).
-    python tools/c2_ll_ratio.py [flags:damping ...]      e.g.  0:0 8:0 0:-1 8:-1     (debug_flags bit 3 = no stripes; damping -1 = off)
+    python tools/c2_ll_ratio.py [flags:damping[:window] ...]     e.g.  0:0 8:0 0:-1 0:0:8
+(debug_flags bit 3 = no stripes; damping -1 = off; window = rows per stripe window, the RFM_STRIPE_WINDOW experiment knob)
 """
 import os
 import sys
@@ -24,7 +25,10 @@ sw = np.ones(N, np.float32)
 x_uf, x_if = np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32)
 cache = {}
 for spec in (sys.argv[1:] or ["0:0"]):
-    flags, damping = spec.split(":")
+    flags, damping, window = (spec.split(":") + [""])[:3]
+    os.environ.pop("RFM_STRIPE_WINDOW", None)
+    if window:
+        os.environ["RFM_STRIPE_WINDOW"] = window
     w = synthetic.init_weights(U, I, F, seed=1492)
     sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=1, seed=1492, debug_flags=int(flags),
                          hogwild_damping=float(damping))

@@ -20,3 +20,22 @@ for epochs in (1, 1, 5, 20):
     dt = time.perf_counter() - t0
     print("host-buffer _fit: epochs=%d  wall %.1f ms  -> %.1f M updates/s (PCIe + plan inclusive); kernel ms/epoch %s" % (
         epochs, dt * 1e3, N * epochs / dt / 1e6, np.round(rep["sgd_kernel_ms"][:3], 2)), flush=True)
+
+# the floor of the boundary: the same host buffers moved by plain copies (pageable numpy memory -> HBM and the weights back), nothing else
+import torch
+dev = torch.device("cuda", 0)
+up = [torch.from_numpy(a) for a in (pairs, sw, csr.offsets, csr.items, w["v_u"], w["v_i"], w["w_i"])]
+down_like = [w["v_u"], w["v_i"], w["w_i"]]
+for _ in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    on = [t.to(dev) for t in up]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    back = [on[4].cpu(), on[5].cpu(), on[6].cpu()]
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    mb_up = sum(t.numel() * t.element_size() for t in up) / 1e6
+    mb_dn = sum(a.nbytes for a in down_like) / 1e6
+    print("plain copies of the same buffers: %.0f MB up %.2f ms (%.1f GB/s), %.0f MB down %.2f ms (%.1f GB/s)" % (
+        mb_up, (t1 - t0) * 1e3, mb_up / (t1 - t0) / 1e3, mb_dn, (t2 - t1) * 1e3, mb_dn / (t2 - t1) / 1e3), flush=True)
