@@ -530,7 +530,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         // sides; stripe = groups x window / 2 rows (<= 256): a smaller stripe would combine more pushes per publication but
         // concentrates the pending pushes on fewer rows, and the atomics no longer bound the kernel.
         const long long g_work = single_group ? 1 : std::min<long long>((long long)grid * gpb, max_groups > 0 ? max_groups : (1LL << 60));
-        stripe_window = (int)std::max<long long>(1, std::min<long long>(32, (long long)(8.0 * (double)cfg->n_items / (double)g_work + 0.5)));
+        stripe_window = (int)std::max<long long>(1, std::min<long long>(32, (long long)((getenv("RFM_STRIPE_FACTOR") ? atof(getenv("RFM_STRIPE_FACTOR")) : 8.0) * (double)cfg->n_items / (double)g_work + 0.5)));   // (RFM_STRIPE_FACTOR: experiment knob)
         if (getenv("RFM_STRIPE_WINDOW")) stripe_window = std::max(1, atoi(getenv("RFM_STRIPE_WINDOW")));                     // (experiment knob)
         if (single_group) stripe_window = 1;      // one group alone: a fresh stripe for every row keeps it exactly sequential
         const int combine = getenv("RFM_STRIPE_COMBINE") ? std::max(1, atoi(getenv("RFM_STRIPE_COMBINE"))) : 2;             // (experiment knob)
