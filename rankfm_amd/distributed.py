@@ -74,17 +74,32 @@ class SharedTables:
         self._starts, self._sizes, self._shapes = starts, sizes, shapes
         self.merge_scale = None          # per-element damping of the summed deltas (None = plain sum)
 
-    def set_merge_damping(self, item_counts_all_ranks, world_size, damping=32.0):
+    def set_merge_damping(self, item_counts_all_ranks, world_size, damping=None, bias_damping=None, learning_rate=0.1):
         """per-element scale of the summed deltas: min(1, M / n_i) clipped below at 1/world_size for item i that all
-        ranks together update n_i times per exchange window; 1/world_size (average) for the dense feature tables"""
+        ranks together update n_i times per exchange window; 1/world_size (average) for the dense feature tables.
+
+        M is the number of updates after which an item's movement stops being linear in their count (the logistic step
+        saturates): summing the replicas' deltas is right below it, averaging them above.  It scales with 1 / learning_rate
+        (default 3.2 / learning_rate: 32 at the reference's 0.1).  The item BIASES are the first to overshoot when many
+        replicas' deltas are summed (a bias step moves the score by eta itself, a factor step by eta |v_u|^2): from four ranks
+        on their M is a quarter of the factors'; two replicas overshoot by at most 2 (the floor of the scale is 1/2) and keep
+        one M, which tracks sequential training best there (|w_i| -12 % after three epochs with the smaller one).  Measured on
+        planted ranking problems with 8 shards (tests/test_distributed_cpu.py, profiles/r02_notes.md): one M = 32 for both is
+        stable but M = 48 already lets the biases diverge (hit_rate@10 0.92 -> 0.21); with the biases at 8 the factors are
+        stable up to M = 64 and diverge at 128; at learning_rate 0.03, M = 32 is three times too strong (0.78 after 14 epochs
+        against 0.935 sequentially) and M = 107 / 27 converges."""
+        if damping is None:
+            damping = 3.2 / max(float(learning_rate), 1e-6)
+        if bias_damping is None:
+            bias_damping = float(damping) / (4.0 if world_size > 2 else 1.0)
         n = torch.as_tensor(np.asarray(item_counts_all_ranks, dtype=np.float64), dtype=torch.float32, device=self.flat.device)
-        s_item = torch.clamp(float(damping) / torch.clamp(n, min=1.0), min=1.0 / world_size, max=1.0)
+        n = torch.clamp(n, min=1.0)
         scale = torch.full_like(self.flat, 1.0 / world_size)
         F = self._shapes["v_i"][1]
         a = self._starts["v_i"]
-        scale[a:a + self._sizes["v_i"]] = s_item.repeat_interleave(F)
+        scale[a:a + self._sizes["v_i"]] = torch.clamp(float(damping) / n, min=1.0 / world_size, max=1.0).repeat_interleave(F)
         a = self._starts["w_i"]
-        scale[a:a + self._sizes["w_i"]] = s_item
+        scale[a:a + self._sizes["w_i"]] = torch.clamp(float(bias_damping) / n, min=1.0 / world_size, max=1.0)
         self.merge_scale = scale if world_size > 1 else None
 
     def begin_epoch(self):
@@ -163,7 +178,7 @@ class ShardedTrainer:
         return total
 
 
-def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=32.0,
+def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=None,
                         syncs_per_epoch=1, **session_kw):
     """wire a rank's shard to the HIP engine: weights are views into the flat bucket, so the engine's in-place
     atomics and the all-reduce act on the same memory"""
@@ -174,7 +189,8 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
                                 minlength=shared.views["w_i"].shape[0]).to(device=device, dtype=torch.float32)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
         # the damping counts updates per exchange window
-        shared.set_merge_damping(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), merge_damping)
+        shared.set_merge_damping(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), merge_damping,
+                                 learning_rate=hyper.get("learning_rate", 0.1))
     if len(shard["csr_offsets"]) <= 1 or len(shard["interactions"]) == 0:
         # a rank without users (more ranks than users, or a few heavy users): it trains nothing but still joins every collective
         def idle_epoch(_views, epoch, part=None):
@@ -196,7 +212,7 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
 
 
 def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,
-                    group=None, device=None, merge_damping=32.0, syncs_per_epoch=1, make_trainer=None):
+                    group=None, device=None, merge_damping=None, syncs_per_epoch=1, make_trainer=None):
     """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
     the SAME arguments and the same numpy seed.
 
