@@ -326,6 +326,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
     if (cfg->debug_shape > 0 && cfg->debug_shape <= (int)(sizeof(kShapes) / sizeof(kShapes[0]))) shape = &kShapes[cfg->debug_shape - 1];
+    if (shape->max_f < cfg->n_factors) return RFM_ERR_BAD_ARG;          // (a debug_shape too narrow for the factor rows)
     const bool serial = cfg->mode == RFM_MODE_SERIAL;
     const bool feat = cfg->has_user_features || cfg->has_item_features;
     // production Hogwild walks user segments of the CSR lists; that needs the lists to BE the interactions.  When they are
