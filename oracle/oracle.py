@@ -55,6 +55,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.rfm_oracle_fit.restype = C.c_int
+        _lib.rfm_oracle_fit_damped.restype = C.c_int
         _lib.rfm_oracle_reg_penalty.restype = C.c_double
     return _lib
 
@@ -88,8 +89,11 @@ def mt_stream(seed, n):
 def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
         alpha, beta, learning_rate, learning_schedule, learning_exponent, max_samples, epochs,
         perms=None, rng_mode=RNG_MT19937, seed=REFERENCE_MT_SEED, epoch_begin=0, membership="linear",
-        has_uf=None, has_if=None, want_negatives=False, row_stripe=None, stripe_rows=0):
+        has_uf=None, has_if=None, want_negatives=False, row_stripe=None, stripe_rows=0, pos_step=None, user_step=None):
     """Run the sequential restatement of `_fit` IN PLACE on the six weight arrays.
+
+    `pos_step` [I] / `user_step` [U] (both or neither): NOT the reference's algorithm any more -- the engine's Hogwild step damping
+    applied sequentially (rfm_oracle_fit_damped), to separate what the damping changes from what asynchrony changes.
 
     Returns dict(ll=float64[epochs], neg=int32[epochs,N] | None, nsamp=int32[epochs,N] | None).
     Raises AssertionError like the reference's assert_finite (_rankfm.pyx:95-103) and ValueError for an
@@ -121,13 +125,19 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
     ll = np.zeros(epochs, dtype=np.float64)
     neg = np.full((epochs, N), -1, dtype=np.int32) if want_negatives else None
     nsamp = np.zeros((epochs, N), dtype=np.int32) if want_negatives else None
-    rc = lib().rfm_oracle_fit(
-        C.byref(prm), _p(interactions, C.c_int32), _p(_f32(sample_weight), C.c_float),
-        _p(csr_off, C.c_int64), _p(csr_items, C.c_int32),
-        _p(_f32(x_uf), C.c_float), _p(_f32(x_if), C.c_float),
-        _p(_f32(w_i), C.c_float), _p(_f32(w_if), C.c_float), _p(_f32(v_u), C.c_float),
-        _p(_f32(v_i), C.c_float), _p(_f32(v_uf), C.c_float), _p(_f32(v_if), C.c_float),
-        _p(perms, C.c_int32), _p(ll, C.c_double), _p(neg, C.c_int32), _p(nsamp, C.c_int32), _p(row_stripe, C.c_int32))
+    args = [C.byref(prm), _p(interactions, C.c_int32), _p(_f32(sample_weight), C.c_float),
+            _p(csr_off, C.c_int64), _p(csr_items, C.c_int32),
+            _p(_f32(x_uf), C.c_float), _p(_f32(x_if), C.c_float),
+            _p(_f32(w_i), C.c_float), _p(_f32(w_if), C.c_float), _p(_f32(v_u), C.c_float),
+            _p(_f32(v_i), C.c_float), _p(_f32(v_uf), C.c_float), _p(_f32(v_if), C.c_float),
+            _p(perms, C.c_int32), _p(ll, C.c_double), _p(neg, C.c_int32), _p(nsamp, C.c_int32), _p(row_stripe, C.c_int32)]
+    if pos_step is None and user_step is None:
+        rc = lib().rfm_oracle_fit(*args)
+    else:
+        pos_step = np.ascontiguousarray(pos_step, dtype=np.float32)
+        user_step = np.ascontiguousarray(user_step, dtype=np.float32)
+        assert pos_step.shape == (I,) and user_step.shape == (U,)
+        rc = lib().rfm_oracle_fit_damped(*args, _p(pos_step, C.c_float), _p(user_step, C.c_float))
     if rc >= 100:
         raise AssertionError("[%s] are not finite" % _ARRAY_NAMES[rc - 100])
     if rc != 0:

@@ -175,12 +175,13 @@ static int all_finite_sum(const float *x, size_t n) {
  *              stripe instead of an item of the whole catalogue (include/rfm_rng.h "negative stripes"), everything else --
  *              rejection of the user's items, the WARP loop -- is unchanged
  */
-int rfm_oracle_fit(const rfm_oracle_params *p,
-                   const int32_t *interactions, const float *sample_weight,
-                   const int64_t *csr_off, const int32_t *csr_items,
-                   const float *x_uf, const float *x_if,
-                   float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
-                   const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe) {
+static int fit_impl(const rfm_oracle_params *p,
+                    const int32_t *interactions, const float *sample_weight,
+                    const int64_t *csr_off, const int32_t *csr_items,
+                    const float *x_uf, const float *x_if,
+                    float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
+                    const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe,
+                    const float *pos_step, const float *user_step) {
     if (!p || p->N < 0 || p->I < 2 || p->F < 1 || p->max_samples < 1) return RFM_ORACLE_BAD_ARG;
     if (p->rng_mode == RFM_RNG_MT19937 && !perms && p->N > 0) return RFM_ORACLE_BAD_ARG;
     const int64_t N = p->N;
@@ -242,7 +243,10 @@ int rfm_oracle_fit(const rfm_oracle_params *p,
             if (neg_out) neg_out[(size_t)e * N + r] = j;
             if (nsamp_out) nsamp_out[(size_t)e * N + r] = sampled;
 
-            w_i[i] += eta * (sw * multiplier * (d_outer * 1.0f) - (d_reg_a * w_i[i]));    /* :279 */
+            /* (rfm_oracle_fit_damped: the engine's Hogwild step damping applied sequentially -- the positive item's step and
+             *  the user's step are scaled, nothing else; both scales are 1 in rfm_oracle_fit) */
+            const float eta_i = pos_step ? eta * pos_step[i] : eta, eta_u = user_step ? eta * user_step[u] : eta;
+            w_i[i] += eta_i * (sw * multiplier * (d_outer * 1.0f) - (d_reg_a * w_i[i]));  /* :279 */
             w_i[j] += eta * (sw * multiplier * (d_outer * -1.0f) - (d_reg_a * w_i[j]));   /* :280 */
 
             const float *xi = x_if + (size_t)i * Q, *xj = x_if + (size_t)j * Q, *xu = x_uf + (size_t)u * P;
@@ -264,8 +268,8 @@ int rfm_oracle_fit(const rfm_oracle_params *p,
                 if (p->has_if)                                                     /* :303-305 */
                     for (int q = 0; q < Q; ++q) d_v_u += v_if[(size_t)q * F + f] * (xi[q] - xj[q]);
 
-                vu[f] += eta * (sw * multiplier * (d_outer * d_v_u) - (d_reg_a * vu[f]));   /* :308 */
-                vi[f] += eta * (sw * multiplier * (d_outer * d_v_i) - (d_reg_a * vi[f]));   /* :309 */
+                vu[f] += eta_u * (sw * multiplier * (d_outer * d_v_u) - (d_reg_a * vu[f])); /* :308 */
+                vi[f] += eta_i * (sw * multiplier * (d_outer * d_v_i) - (d_reg_a * vi[f])); /* :309 */
                 vj[f] += eta * (sw * multiplier * (d_outer * d_v_j) - (d_reg_a * vj[f]));   /* :310 */
 
                 if (p->has_uf)                                                     /* :313-318 (post-update v_i) */
@@ -294,6 +298,32 @@ int rfm_oracle_fit(const rfm_oracle_params *p,
         if (!all_finite_sum(v_if, (size_t)Q * F)) return RFM_ORACLE_NONFINITE_BASE + 5;
     }
     return RFM_ORACLE_OK;
+}
+
+int rfm_oracle_fit(const rfm_oracle_params *p,
+                   const int32_t *interactions, const float *sample_weight,
+                   const int64_t *csr_off, const int32_t *csr_items,
+                   const float *x_uf, const float *x_if,
+                   float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
+                   const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe) {
+    return fit_impl(p, interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
+                    perms, ll_out, neg_out, nsamp_out, row_stripe, NULL, NULL);
+}
+
+/* NOT the reference's algorithm: the same sequential loop with the engine's Hogwild step damping applied --
+ *   pos_step  float [I]  scale of the POSITIVE item's step (bias and factor row), the engine's pos_scale
+ *   user_step float [U]  scale of the user's step, the engine's min(1, user_cap / degree)
+ * so that a test can separate what the damping changes (this against rfm_oracle_fit: a deliberate, documented change of the
+ * optimiser) from what asynchronous execution changes (the engine against this). */
+int rfm_oracle_fit_damped(const rfm_oracle_params *p,
+                          const int32_t *interactions, const float *sample_weight,
+                          const int64_t *csr_off, const int32_t *csr_items,
+                          const float *x_uf, const float *x_if,
+                          float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
+                          const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe,
+                          const float *pos_step, const float *user_step) {
+    return fit_impl(p, interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
+                    perms, ll_out, neg_out, nsamp_out, row_stripe, pos_step, user_step);
 }
 
 /* _rankfm.pyx:106-116  (double accumulation like numpy's float64 `penalty`) */

@@ -1,0 +1,68 @@
+"""The oracle's damped variant (oracle/rfm_oracle.c: rfm_oracle_fit_damped) -- the engine's Hogwild step damping applied to the
+SEQUENTIAL algorithm, so that GPU tests can tell the deliberate change of the optimiser from the effect of asynchrony.
+CPU-only checks of the variant itself; the reference-pinned entry point is unchanged (tests/test_oracle_golden.py)."""
+import numpy as np
+
+from rankfm_amd import synthetic
+
+
+def _fit(oracle, w, pairs, csr, epochs=2, **kw):
+    g = {k: v.copy() for k, v in w.items()}
+    U, I = len(w["v_u"]), len(w["w_i"])
+    out = oracle.fit(pairs, np.ones(len(pairs), np.float32), csr.offsets, csr.items, np.zeros((U, 1), np.float32),
+                     np.zeros((I, 1), np.float32), g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"], 0.01, 0.1, 0.1,
+                     "constant", 0.25, 1, epochs, perms=None, rng_mode=oracle.RNG_COUNTER, seed=7, membership="binary", **kw)
+    return g, out
+
+
+def test_unit_scales_are_the_plain_oracle_bit_for_bit(oracle):
+    U, I, N, F = 60, 40, 1500, 8
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=3)
+    w = synthetic.init_weights(U, I, F, seed=4)
+    a, oa = _fit(oracle, w, pairs, csr)
+    b, ob = _fit(oracle, w, pairs, csr, pos_step=np.ones(I, np.float32), user_step=np.ones(U, np.float32))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(oa["ll"], ob["ll"])
+
+
+def test_zero_scales_freeze_exactly_what_they_scale(oracle):
+    U, I, N, F = 60, 40, 1500, 8
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=3)
+    w = synthetic.init_weights(U, I, F, seed=4)
+    g, _ = _fit(oracle, w, pairs, csr, pos_step=np.ones(I, np.float32), user_step=np.zeros(U, np.float32))
+    assert np.array_equal(g["v_u"], w["v_u"]) and not np.array_equal(g["v_i"], w["v_i"])
+    # one interaction (user 0, item 0) over three items: with pos_step[0] = 0 item 0 never moves, the drawn negative does
+    pairs1 = np.array([[0, 0]], np.int32)
+    csr1 = type(csr).from_pairs(pairs1[:, 0], pairs1[:, 1], 1)
+    w1 = synthetic.init_weights(1, 3, 4, seed=5)
+    g, out = _fit(oracle, w1, pairs1, csr1, epochs=1, pos_step=np.array([0, 1, 1], np.float32), user_step=np.ones(1, np.float32),
+                  want_negatives=True)
+    j = int(out["neg"][0, 0])
+    assert j in (1, 2)
+    assert np.array_equal(g["v_i"][0], w1["v_i"][0]) and g["w_i"][0] == w1["w_i"][0]
+    assert not np.array_equal(g["v_i"][j], w1["v_i"][j]) and not np.array_equal(g["v_u"], w1["v_u"])
+
+
+def test_one_damped_step_by_hand(oracle):
+    """a single interaction: the update block (rankfm/_rankfm.pyx:276-310) recomputed in numpy with eta_i = s_i eta, eta_u = s_u eta"""
+    pairs1 = np.array([[0, 0]], np.int32)
+    from rankfm_amd._rankfm import UserItemsCSR
+    csr1 = UserItemsCSR.from_pairs(pairs1[:, 0], pairs1[:, 1], 1)
+    w = synthetic.init_weights(1, 3, 4, seed=6)
+    for k in ("v_u", "v_i"):
+        w[k] = (w[k] * 30).astype(np.float32)              # large enough for the logistic term to matter
+    s_i, s_u, eta, alpha = 0.25, 0.5, 0.1, 0.01
+    g, out = _fit(oracle, w, pairs1, csr1, epochs=1, pos_step=np.array([s_i, 1, 1], np.float32), user_step=np.array([s_u], np.float32),
+                  want_negatives=True)
+    j = int(out["neg"][0, 0])
+    vu, vi, vj = (w["v_u"][0].astype(np.float64), w["v_i"][0].astype(np.float64), w["v_i"][j].astype(np.float64))
+    pu = (w["w_i"][0] + vu @ vi) - (w["w_i"][j] + vu @ vj)
+    d = 1.0 / (np.exp(pu) + 1.0)
+    mult = np.log((3 - 1) // 1) / np.log(3)
+    reg = 2 * alpha
+    np.testing.assert_allclose(g["v_u"][0], vu + s_u * eta * (mult * d * (vi - vj) - reg * vu), rtol=2e-6)
+    np.testing.assert_allclose(g["v_i"][0], vi + s_i * eta * (mult * d * vu - reg * vi), rtol=2e-6)
+    np.testing.assert_allclose(g["v_i"][j], vj + eta * (mult * d * -vu - reg * vj), rtol=2e-6)
+    np.testing.assert_allclose(g["w_i"][0], w["w_i"][0] + s_i * eta * (mult * d - reg * w["w_i"][0]), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(g["w_i"][j], w["w_i"][j] + eta * (-mult * d - reg * w["w_i"][j]), rtol=2e-6, atol=1e-9)
