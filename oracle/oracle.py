@@ -55,7 +55,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB_PATH)
         _lib.rfm_oracle_fit.restype = C.c_int
-        _lib.rfm_oracle_fit_damped.restype = C.c_int
+        _lib.rfm_oracle_fit_ex.restype = C.c_int
         _lib.rfm_oracle_reg_penalty.restype = C.c_double
     return _lib
 
@@ -93,9 +93,12 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
     """Run the sequential restatement of `_fit` IN PLACE on the six weight arrays.
 
     `pos_step` [I] / `user_step` [U] (both or neither): NOT the reference's algorithm any more -- the engine's Hogwild step damping
-    applied sequentially (rfm_oracle_fit_damped), to separate what the damping changes from what asynchrony changes.
+    applied sequentially (rfm_oracle_fit_ex), to separate what the damping changes from what asynchrony changes.
 
-    Returns dict(ll=float64[epochs], neg=int32[epochs,N] | None, nsamp=int32[epochs,N] | None).
+    Returns dict(ll=float64[epochs], ll64=float64[epochs], neg=int32[epochs,N] | None, nsamp=int32[epochs,N] | None): `ll` is the
+    reference's float-accumulated log-likelihood (what it prints; pinned by the golden vectors), `ll64` the same sum in double --
+    at millions of rows the float accumulator rounds away every small term (~0.5 % at 5 M rows), so statistical comparisons of a
+    trajectory should use `ll64`.
     Raises AssertionError like the reference's assert_finite (_rankfm.pyx:95-103) and ValueError for an
     unknown learning schedule (_rankfm.pyx:225).
     """
@@ -131,18 +134,17 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
             _p(_f32(w_i), C.c_float), _p(_f32(w_if), C.c_float), _p(_f32(v_u), C.c_float),
             _p(_f32(v_i), C.c_float), _p(_f32(v_uf), C.c_float), _p(_f32(v_if), C.c_float),
             _p(perms, C.c_int32), _p(ll, C.c_double), _p(neg, C.c_int32), _p(nsamp, C.c_int32), _p(row_stripe, C.c_int32)]
-    if pos_step is None and user_step is None:
-        rc = lib().rfm_oracle_fit(*args)
-    else:
+    ll64 = np.zeros(epochs, dtype=np.float64)
+    if pos_step is not None or user_step is not None:
         pos_step = np.ascontiguousarray(pos_step, dtype=np.float32)
         user_step = np.ascontiguousarray(user_step, dtype=np.float32)
         assert pos_step.shape == (I,) and user_step.shape == (U,)
-        rc = lib().rfm_oracle_fit_damped(*args, _p(pos_step, C.c_float), _p(user_step, C.c_float))
+    rc = lib().rfm_oracle_fit_ex(*args, _p(pos_step, C.c_float), _p(user_step, C.c_float), _p(ll64, C.c_double))
     if rc >= 100:
         raise AssertionError("[%s] are not finite" % _ARRAY_NAMES[rc - 100])
     if rc != 0:
         raise ValueError("rfm_oracle_fit: bad argument (rc=%d)" % rc)
-    return dict(ll=ll, neg=neg, nsamp=nsamp)
+    return dict(ll=ll, ll64=ll64, neg=neg, nsamp=nsamp)
 
 
 def reg_penalty(alpha, beta, w_i, w_if, v_u, v_i, v_uf, v_if):

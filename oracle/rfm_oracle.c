@@ -181,7 +181,7 @@ static int fit_impl(const rfm_oracle_params *p,
                     const float *x_uf, const float *x_if,
                     float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
                     const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe,
-                    const float *pos_step, const float *user_step) {
+                    const float *pos_step, const float *user_step, double *ll64_out) {
     if (!p || p->N < 0 || p->I < 2 || p->F < 1 || p->max_samples < 1) return RFM_ORACLE_BAD_ARG;
     if (p->rng_mode == RFM_RNG_MT19937 && !perms && p->N > 0) return RFM_ORACLE_BAD_ARG;
     const int64_t N = p->N;
@@ -203,6 +203,7 @@ static int fit_impl(const rfm_oracle_params *p,
         else return RFM_ORACLE_BAD_ARG;                                            /* :224-225 ValueError */
         const uint32_t ekey = rfm_epoch_key(p->seed, (uint32_t)epoch);
         float log_likelihood = 0.0f;                                               /* :228 */
+        double log_likelihood64 = 0.0;     /* the same sum without the float accumulator's rounding (ll64_out) */
 
         for (int64_t r = 0; r < N; ++r) {                                          /* :230 */
             const int64_t row = perms ? perms[(size_t)e * N + r]
@@ -215,8 +216,8 @@ static int fit_impl(const rfm_oracle_params *p,
             uint32_t attempt = 0;
 
             const float ut_ui = utility(&m, u, i);                                 /* :239 */
-            int min_index = -1, sampled = 0, j;
-            float min_pu = 1e6f, pu;                                               /* :244-245 */
+            int min_index = -1, sampled = 0, j = 0;
+            float min_pu = 1e6f, pu = 0.0f;                                        /* :244-245 */
             for (sampled = 1; sampled <= p->max_samples; ++sampled) {              /* :247 */
                 for (;;) {                                                         /* :250-253 */
                     if (p->rng_mode == RFM_RNG_MT19937) j = (int)(mt_next(&mt) % (uint32_t)I);
@@ -238,12 +239,14 @@ static int fit_impl(const rfm_oracle_params *p,
             if (min_index >= 0) { j = min_index; pu = min_pu; }
             /* :269 -- C integer division inside the log (cdivision=True) */
             const float multiplier = (float)(log((double)((I - 1) / sampled)) / log((double)I));
-            log_likelihood = (float)((double)log_likelihood + log(1.0 / (1.0 + exp(-(double)pu))));   /* :270 */
+            const double log_sig = log(1.0 / (1.0 + exp(-(double)pu)));
+            log_likelihood = (float)((double)log_likelihood + log_sig);            /* :270 */
+            log_likelihood64 += log_sig;
             const float d_outer = (float)(1.0 / (exp((double)pu) + 1.0));         /* :276 */
             if (neg_out) neg_out[(size_t)e * N + r] = j;
             if (nsamp_out) nsamp_out[(size_t)e * N + r] = sampled;
 
-            /* (rfm_oracle_fit_damped: the engine's Hogwild step damping applied sequentially -- the positive item's step and
+            /* (rfm_oracle_fit_ex: the engine's Hogwild step damping applied sequentially -- the positive item's step and
              *  the user's step are scaled, nothing else; both scales are 1 in rfm_oracle_fit) */
             const float eta_i = pos_step ? eta * pos_step[i] : eta, eta_u = user_step ? eta * user_step[u] : eta;
             w_i[i] += eta_i * (sw * multiplier * (d_outer * 1.0f) - (d_reg_a * w_i[i]));  /* :279 */
@@ -289,6 +292,7 @@ static int fit_impl(const rfm_oracle_params *p,
             }
         }
         if (ll_out) ll_out[e] = (double)log_likelihood;
+        if (ll64_out) ll64_out[e] = log_likelihood64;
         /* :329 assert_finite, same array order as :98-103 */
         if (!all_finite_sum(w_i, (size_t)I)) return RFM_ORACLE_NONFINITE_BASE + 0;
         if (!all_finite_sum(w_if, (size_t)Q)) return RFM_ORACLE_NONFINITE_BASE + 1;
@@ -307,23 +311,29 @@ int rfm_oracle_fit(const rfm_oracle_params *p,
                    float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
                    const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe) {
     return fit_impl(p, interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
-                    perms, ll_out, neg_out, nsamp_out, row_stripe, NULL, NULL);
+                    perms, ll_out, neg_out, nsamp_out, row_stripe, NULL, NULL, NULL);
 }
 
-/* NOT the reference's algorithm: the same sequential loop with the engine's Hogwild step damping applied --
- *   pos_step  float [I]  scale of the POSITIVE item's step (bias and factor row), the engine's pos_scale
- *   user_step float [U]  scale of the user's step, the engine's min(1, user_cap / degree)
- * so that a test can separate what the damping changes (this against rfm_oracle_fit: a deliberate, documented change of the
- * optimiser) from what asynchronous execution changes (the engine against this). */
-int rfm_oracle_fit_damped(const rfm_oracle_params *p,
-                          const int32_t *interactions, const float *sample_weight,
-                          const int64_t *csr_off, const int32_t *csr_items,
-                          const float *x_uf, const float *x_if,
-                          float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
-                          const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe,
-                          const float *pos_step, const float *user_step) {
+/* The extended entry point of the checker:
+ *   pos_step, user_step (both or neither)  NOT the reference's algorithm any more: the same sequential loop with the engine's
+ *              Hogwild step damping applied -- pos_step float [I] scales the POSITIVE item's step (bias and
+ *              factor row; the engine's pos_scale), user_step float [U] the user's step (the engine's min(1, user_cap / degree)) --
+ *              so that a test can separate what the damping changes (this against rfm_oracle_fit: a deliberate, documented change
+ *              of the optimiser) from what asynchronous execution changes (the engine against this);
+ *   ll64_out   double [epochs] or NULL: the epoch's log-likelihood summed in DOUBLE.  The reference accumulates it in a float
+ *              (`cdef float log_likelihood`, :228, :270): once the running sum passes 2^20 every term below 1/16 is rounded away
+ *              (well-classified pairs contribute ~0.01), so at 5 M rows its printed value is ~0.5 % too small in magnitude and at
+ *              50 M rows it is meaningless.  ll_out keeps the reference's arithmetic (the golden vectors pin it); statistical
+ *              comparisons at scale should use this one. */
+int rfm_oracle_fit_ex(const rfm_oracle_params *p,
+                      const int32_t *interactions, const float *sample_weight,
+                      const int64_t *csr_off, const int32_t *csr_items,
+                      const float *x_uf, const float *x_if,
+                      float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
+                      const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe,
+                      const float *pos_step, const float *user_step, double *ll64_out) {
     return fit_impl(p, interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
-                    perms, ll_out, neg_out, nsamp_out, row_stripe, pos_step, user_step);
+                    perms, ll_out, neg_out, nsamp_out, row_stripe, pos_step, user_step, ll64_out);
 }
 
 /* _rankfm.pyx:106-116  (double accumulation like numpy's float64 `penalty`) */

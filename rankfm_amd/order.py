@@ -85,18 +85,17 @@ def _visit(csr_offsets, seed, epoch):
     return np.repeat(b, l) + within, np.repeat(np.arange(S, dtype=np.int64), l), t, l, ek
 
 
-def row_stripes(csr_offsets, seed, epoch, geometry):
-    """int32 [N]: the first position of the negative stripe (include/rfm_rng.h) every CSR position draws from in `epoch`, for the launch geometry the
-    engine reported (DeviceSession.geometry() / the `geometry` entry of `_fit`'s report).  Restates the schedule of
-    sgd_segments_kernel<STRIPE>: row group g of a launch walks the segments at order positions p0 + g, p0 + g + n_groups, ...;
-    its k-th row of the launch lies in window k // stripe_window of its workgroup g // groups_per_workgroup; the stripe of
-    (workgroup, window) starts at rfm_stripe_start."""
-    R, RW = geometry["stripe_rows"], geometry["stripe_window"]
-    n_items = int(geometry["n_items"])
+def row_schedule(csr_offsets, seed, epoch, geometry):
+    """Where and when the launch described by `geometry` processes every row of `epoch`: per visited row (in the enumeration of
+    `epoch_positions`) its CSR position `pos`, segment-order position `sp`, index `t` in its segment, and -- restating the walk of
+    sgd_segments_kernel -- the row group that processes it (`group`: group g of a launch walks the segments at order positions
+    p0 + g, p0 + g + n_groups, ...), the iteration of that group's loop at which it does (`it`: rows the group has done in the
+    launch before), its workgroup and launch; plus `seg_len` by sp and the epoch key."""
     pos, sp, t, seg_len, ek = _visit(csr_offsets, seed, epoch)
     S = len(seg_len)
-    n_groups = 1 if geometry["single_group"] else int(geometry["working_groups"])
-    gpw, grid = int(geometry["groups_per_workgroup"]), (1 if geometry["single_group"] else int(geometry["workgroups"]))
+    single = bool(geometry["single_group"])
+    n_groups = 1 if single else int(geometry["working_groups"])
+    gpw = int(geometry["groups_per_workgroup"])
     upl = int(geometry["units_per_launch"])
     u_begin, u_end = 0, S
     if geometry.get("epoch_part"):
@@ -108,24 +107,35 @@ def row_stripes(csr_offsets, seed, epoch, geometry):
     for launch, p0 in enumerate(range(u_begin, u_end, upl)):
         p1 = min(p0 + upl, u_end)
         k = np.arange(p1 - p0, dtype=np.int64)
-        stride = 1 if geometry["single_group"] else n_groups
+        stride = 1 if single else n_groups
         rounds = (len(k) + stride - 1) // stride
         m = np.zeros(rounds * stride, dtype=np.int64)
         m[:len(k)] = seg_len[p0:p1]
         m = m.reshape(rounds, stride)
         before = (np.cumsum(m, axis=0) - m).reshape(-1)[:len(k)]
-        if geometry["single_group"]:               # one group walks the launch's segments one after the other
+        if single:                                 # one group walks the launch's segments one after the other
             before = np.cumsum(seg_len[p0:p1]) - seg_len[p0:p1]
         start_iter[p0:p1] = before
         launch_of[p0:p1] = launch
-        group_of[p0:p1] = 0 if geometry["single_group"] else k % n_groups
-    it = start_iter[sp] + t
-    window = it // RW
-    wg = group_of[sp] // gpw
-    salt = mix32((np.uint64(ek) ^ ((np.uint64(0x68E31DA4) + launch_of[sp].astype(np.uint64)) & _M32)) & _M32)
-    stripe = ((window * grid + wg).astype(np.uint64) * np.uint64(R) + salt) % np.uint64(n_items)       # rfm_stripe_start
-    out = np.zeros(len(pos), dtype=np.int32)
-    out[pos] = stripe.astype(np.int32)
+        group_of[p0:p1] = 0 if single else k % n_groups
+    return dict(pos=pos, sp=sp, t=t, seg_len=seg_len, epoch_key=ek, it=start_iter[sp] + t, group=group_of[sp],
+                workgroup=group_of[sp] // gpw, launch=launch_of[sp])
+
+
+def row_stripes(csr_offsets, seed, epoch, geometry):
+    """int32 [N]: the first position of the negative stripe (include/rfm_rng.h) every CSR position draws from in `epoch`, for the launch geometry the
+    engine reported (DeviceSession.geometry() / the `geometry` entry of `_fit`'s report).  Restates the schedule of
+    sgd_segments_kernel<STRIPE>: the k-th row a group processes in a launch (row_schedule) lies in window k // stripe_window of
+    its workgroup; the stripe of (workgroup, window) starts at rfm_stripe_start."""
+    R, RW = geometry["stripe_rows"], geometry["stripe_window"]
+    n_items = int(geometry["n_items"])
+    sch = row_schedule(csr_offsets, seed, epoch, geometry)
+    grid = 1 if geometry["single_group"] else int(geometry["workgroups"])
+    window = sch["it"] // RW
+    salt = mix32((np.uint64(sch["epoch_key"]) ^ ((np.uint64(0x68E31DA4) + sch["launch"].astype(np.uint64)) & _M32)) & _M32)
+    stripe = ((window * grid + sch["workgroup"]).astype(np.uint64) * np.uint64(R) + salt) % np.uint64(n_items)       # rfm_stripe_start
+    out = np.zeros(len(sch["pos"]), dtype=np.int32)
+    out[sch["pos"]] = stripe.astype(np.int32)
     return out
 
 

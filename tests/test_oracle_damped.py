@@ -1,4 +1,4 @@
-"""The oracle's damped variant (oracle/rfm_oracle.c: rfm_oracle_fit_damped) -- the engine's Hogwild step damping applied to the
+"""The oracle's damped variant (oracle/rfm_oracle.c: rfm_oracle_fit_ex) -- the engine's Hogwild step damping applied to the
 SEQUENTIAL algorithm, so that GPU tests can tell the deliberate change of the optimiser from the effect of asynchrony.
 CPU-only checks of the variant itself; the reference-pinned entry point is unchanged (tests/test_oracle_golden.py)."""
 import numpy as np
@@ -66,3 +66,15 @@ def test_one_damped_step_by_hand(oracle):
     np.testing.assert_allclose(g["v_i"][j], vj + eta * (mult * d * -vu - reg * vj), rtol=2e-6)
     np.testing.assert_allclose(g["w_i"][0], w["w_i"][0] + s_i * eta * (mult * d - reg * w["w_i"][0]), rtol=2e-6, atol=1e-9)
     np.testing.assert_allclose(g["w_i"][j], w["w_i"][j] + eta * (-mult * d - reg * w["w_i"][j]), rtol=2e-6, atol=1e-9)
+
+
+def test_ll64_is_the_float_accumulators_sum_without_its_rounding(oracle):
+    """`ll` restates the reference's float accumulator (rankfm/_rankfm.pyx:228, :270); `ll64` sums the same terms in double.  On a
+    small problem they agree to float precision; the divergence at millions of rows (the accumulator's spacing passes the size of
+    the small terms: ~0.5 % at 5 M rows) is documented in profiles/r02_notes.md."""
+    U, I, N, F = 60, 40, 1500, 8
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=3)
+    w = synthetic.init_weights(U, I, F, seed=4)
+    _, out = _fit(oracle, w, pairs, csr, epochs=3)
+    assert out["ll64"].shape == (3,) and np.all(out["ll64"] < 0)
+    np.testing.assert_allclose(out["ll"], out["ll64"], rtol=2e-6)
