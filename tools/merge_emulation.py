@@ -1,0 +1,73 @@
+"""CPU-only analysis: 2 / 4 / 8 user shards trained by the sequential oracle from the same epoch-start tables and merged like the
+ranks of rankfm_amd/distributed.py do (SharedTables.merge_scale), against sequential training of the whole data, on the
+MovieLens-1M-shaped planted problem.
+    python tools/merge_emulation.py [epochs] [learning_rate]
+Edit the (world, M factors, M biases) list at the bottom for other settings.  Numbers in profiles/r02_notes.md.
+(test / analysis infrastructure: uses oracle/)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import oracle as orc
+from rankfm_amd import synthetic
+from rankfm_amd._rankfm import UserItemsCSR
+from rankfm_amd.distributed import SHARED_NAMES, SharedTables, shard_boundaries, take_user_shard
+orc.build()
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+LR = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
+d = synthetic.make_planted(seed=0)
+pairs, test = d["train"], d["test"]
+U, I, F = 6040, 3706, 20
+N = len(pairs)
+csr = UserItemsCSR.from_pairs(pairs[:, 0], pairs[:, 1], U)
+w = synthetic.init_weights(U, I, F, seed=3)
+sw = np.ones(N, np.float32)
+z_i = np.zeros((I, 1), np.float32)
+test_users = np.unique(test[:, 0])
+tcsr = UserItemsCSR.from_pairs(test[:, 0], test[:, 1], U)
+def hit_rate(v_u, v_i, w_i, k=10):
+    hits = 0
+    for u0 in range(0, len(test_users), 512):
+        us = test_users[u0:u0 + 512]
+        S = v_u[us] @ v_i.T + w_i
+        for r, u in enumerate(us):
+            S[r, csr.items[csr.offsets[u]:csr.offsets[u + 1]]] = -np.inf
+        top = np.argpartition(-S, k, axis=1)[:, :k]
+        for r, u in enumerate(us):
+            hits += bool(np.intersect1d(top[r], tcsr.items[tcsr.offsets[u]:tcsr.offsets[u + 1]]).size)
+    return hits / len(test_users)
+o = {k: v.copy() for k, v in w.items()}
+out = orc.fit(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), z_i, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"],
+              0.01, 0.1, LR, "constant", 0.25, 1, E, perms=None, rng_mode=orc.RNG_COUNTER, seed=1, membership="binary")
+ll_seq = out["ll"]
+print("sequential: hit_rate@10 %.4f" % hit_rate(o["v_u"], o["v_i"], o["w_i"]), "LL/N", np.round(ll_seq / N, 4), flush=True)
+counts = np.bincount(pairs[:, 1], minlength=I)
+for world, M, MW in ((8, 32.0, 8.0), (8, 107.0, 27.0), (8, 213.0, 27.0), (8, 107.0, 107.0)):
+    bounds = shard_boundaries(csr.offsets, world)
+    shards = [take_user_shard(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), w["v_u"].copy(), bounds[r], bounds[r + 1]) for r in range(world)]
+    ref = SharedTables({k: w[k].copy() for k in SHARED_NAMES}, torch.device("cpu"))
+    ref.set_merge_damping(counts, world, damping=M)
+    a = ref._starts["w_i"]
+    nn = torch.as_tensor(counts.astype(np.float32))
+    ref.merge_scale[a:a + ref._sizes["w_i"]] = torch.clamp(MW / torch.clamp(nn, min=1.0), min=1.0 / world, max=1.0)
+    ll = np.zeros(E)
+    for e in range(E):
+        start = ref.flat.clone(); total = torch.zeros_like(start)
+        for k in range(world):
+            ref.flat.copy_(start)
+            t = {n: ref.views[n].numpy() for n in SHARED_NAMES}
+            s = shards[k]
+            r = orc.fit(s["interactions"], s["sample_weight"], s["csr_offsets"], s["csr_items"], np.zeros((len(s["v_u"]), 1), np.float32), z_i,
+                        t["w_i"], t["w_if"], s["v_u"], t["v_i"], t["v_uf"], t["v_if"], 0.01, 0.1, LR, "constant", 0.25, 1, 1, perms=None,
+                        rng_mode=orc.RNG_COUNTER, seed=100 + k, epoch_begin=e, membership="binary")
+            ll[e] += r["ll"][0]
+            total += ref.flat - start
+        ref.flat.copy_(start + ref.merge_scale * total)
+    v_u = np.concatenate([s["v_u"] for s in shards])
+    v_i, w_i = ref.views["v_i"].numpy(), ref.views["w_i"].numpy()
+    nr = [float(np.linalg.norm(a) / np.linalg.norm(b) - 1) for a, b in ((v_u, o["v_u"]), (v_i, o["v_i"]), (w_i, o["w_i"]))]
+    print("world %d M %g MW " % (world, M) + str(MW) + ": hit_rate@10 %.4f  LL/seq-1 %s  norms-1 %s" % (hit_rate(v_u, v_i, w_i), np.round(ll / ll_seq - 1, 3), np.round(nr, 3)), flush=True)
