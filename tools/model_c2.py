@@ -1,6 +1,6 @@
 """CPU-only analysis: the execution model of the stripe kernel (oracle/rfm_async_sim.c) on BASELINE config 2 at full size, two epochs,
 against the sequential limit of the same schedule (same draws, everything visible at once, log-likelihood summed in double).
-    python tools/model_c2.py w=24 w=24,skew=12 w=24,rows=97,ph=2,skew=24 rows=0 ...
+    [SEGROWS=16] python tools/model_c2.py w=24 w=24,skew=12 w=24,rows=97,ph=2,skew=24 rows=0 ...
 keys: w = stripe window (rows per group), rows = stripe rows (0: no stripes), skew = workgroups lag by up to that many rounds,
 ph = phases of the stripe schedule (experiment), mean = factor of the mean-field view of the positive item.
 Numbers in profiles/r02_notes.md.  (test / analysis infrastructure: uses oracle/)"""
@@ -20,6 +20,7 @@ sw = np.ones(N, np.float32)
 by_csr = np.lexsort((pairs[:, 1], pairs[:, 0]))
 pairs_csr = np.ascontiguousarray(pairs[by_csr])
 E, seed = 2, 1492
+order.SEGMENT_ROWS = int(os.environ.get("SEGROWS", "32"))      # rows per user segment (32 in the engine)
 n_seg = len(order.segments(csr.offsets)[0])
 cnt = np.bincount(pairs[:, 1], minlength=I)
 def run(geo, E, **kw):
