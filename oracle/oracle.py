@@ -35,6 +35,7 @@ class OracleParams(C.Structure):
         ("seed", C.c_uint32),
         ("membership", C.c_int32),
         ("stripe_rows", C.c_int32),
+        ("table_every", C.c_int32), ("table_step", C.c_float),
     ]
 
 
@@ -89,7 +90,7 @@ def mt_stream(seed, n):
 def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
         alpha, beta, learning_rate, learning_schedule, learning_exponent, max_samples, epochs,
         perms=None, rng_mode=RNG_MT19937, seed=REFERENCE_MT_SEED, epoch_begin=0, membership="linear",
-        has_uf=None, has_if=None, want_negatives=False, row_stripe=None, stripe_rows=0, pos_step=None, user_step=None):
+        has_uf=None, has_if=None, want_negatives=False, row_stripe=None, stripe_rows=0, pos_step=None, user_step=None, table_every=0, table_step=0.0):
     """Run the sequential restatement of `_fit` IN PLACE on the six weight arrays.
 
     `pos_step` [I] / `user_step` [U] (both or neither): NOT the reference's algorithm any more -- the engine's Hogwild step damping
@@ -118,7 +119,8 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
         schedule=0 if learning_schedule == "constant" else 1,
         learning_exponent=learning_exponent, max_samples=max_samples,
         epochs=epochs, epoch_begin=epoch_begin, rng_mode=rng_mode, seed=seed,
-        membership=0 if membership == "linear" else 1, stripe_rows=int(stripe_rows))
+        membership=0 if membership == "linear" else 1, stripe_rows=int(stripe_rows),
+        table_every=int(table_every), table_step=float(table_step))      # (analysis options, rfm_oracle.c; 0 / 0 = the reference)
     if row_stripe is not None:
         row_stripe = np.ascontiguousarray(row_stripe, dtype=np.int32)
         assert row_stripe.shape == (epochs, N) and rng_mode == RNG_COUNTER and stripe_rows >= 1

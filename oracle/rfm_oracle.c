@@ -145,6 +145,11 @@ typedef struct {
     uint32_t seed;                   /* MT seed (reference: 1492) or counter seed */
     int32_t membership;              /* 0 linear (lsearch), 1 binary */
     int32_t stripe_rows;             /* counter mode with `row_stripe`: items per negative stripe (include/rfm_rng.h) */
+    /* analysis only (NOT the reference's algorithm; 0 / 0 = the reference): the dense feature tables are updated on every
+     * `table_every`-th visited row only, with their step scaled by `table_step` -- a sequential stand-in for the engine's table
+     * trainer, which trains the tables on a sample of the rows while every row reads them (rfm_sgd.hpp, sgd_features_kernel) */
+    int32_t table_every;
+    float table_step;
 } rfm_oracle_params;
 
 /* return codes */
@@ -253,10 +258,12 @@ static int fit_impl(const rfm_oracle_params *p,
             w_i[j] += eta * (sw * multiplier * (d_outer * -1.0f) - (d_reg_a * w_i[j]));   /* :280 */
 
             const float *xi = x_if + (size_t)i * Q, *xj = x_if + (size_t)j * Q, *xu = x_uf + (size_t)u * P;
-            if (p->has_if)                                                         /* :283-286 */
+            const int do_tab = p->table_every <= 1 || r % p->table_every == 0;     /* (analysis option; always 1 for the reference) */
+            const float eta_t = p->table_step > 0.0f ? eta * p->table_step : eta;
+            if (p->has_if && do_tab)                                               /* :283-286 */
                 for (int q = 0; q < Q; ++q) {
                     const float d_w_if = xi[q] - xj[q];
-                    w_if[q] += eta * (sw * multiplier * (d_outer * d_w_if) - (d_reg_b * w_if[q]));
+                    w_if[q] += eta_t * (sw * multiplier * (d_outer * d_w_if) - (d_reg_b * w_if[q]));
                 }
 
             float *vu = v_u + (size_t)u * F, *vi = v_i + (size_t)i * F, *vj = v_i + (size_t)j * F;
@@ -275,19 +282,19 @@ static int fit_impl(const rfm_oracle_params *p,
                 vi[f] += eta_i * (sw * multiplier * (d_outer * d_v_i) - (d_reg_a * vi[f])); /* :309 */
                 vj[f] += eta * (sw * multiplier * (d_outer * d_v_j) - (d_reg_a * vj[f]));   /* :310 */
 
-                if (p->has_uf)                                                     /* :313-318 (post-update v_i) */
+                if (p->has_uf && do_tab)                                           /* :313-318 (post-update v_i) */
                     for (int pp = 0; pp < P; ++pp) {
                         if (xu[pp] == 0.0f) continue;
                         const float d_v_uf = xu[pp] * (vi[f] - vj[f]);
                         float *t = v_uf + (size_t)pp * F + f;
-                        *t += eta * (sw * multiplier * (d_outer * d_v_uf) - (d_reg_b * *t));
+                        *t += eta_t * (sw * multiplier * (d_outer * d_v_uf) - (d_reg_b * *t));
                     }
-                if (p->has_if)                                                     /* :321-326 (post-update v_u) */
+                if (p->has_if && do_tab)                                           /* :321-326 (post-update v_u) */
                     for (int q = 0; q < Q; ++q) {
                         if (xi[q] - xj[q] == 0.0f) continue;
                         const float d_v_if = (xi[q] - xj[q]) * vu[f];
                         float *t = v_if + (size_t)q * F + f;
-                        *t += eta * (sw * multiplier * (d_outer * d_v_if) - (d_reg_b * *t));
+                        *t += eta_t * (sw * multiplier * (d_outer * d_v_if) - (d_reg_b * *t));
                     }
             }
         }
