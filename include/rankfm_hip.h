@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RFM_ABI_VERSION 2
+#define RFM_ABI_VERSION 3
 
 typedef enum rfm_status {
     RFM_OK = 0,
@@ -151,6 +151,8 @@ typedef struct rfm_fit_report {
     int64_t n_units;               /* user segments (or rows) per epoch */
     int32_t stripe_rows;           /* items per negative stripe (include/rfm_rng.h), 0 = draws over the whole catalogue */
     int32_t stripe_window;         /* rows per group between stripe changes */
+    int32_t segment_rows;          /* longest user segment of the plan (32; 16 when negative stripes are used), 0 = rows kernel */
+    int32_t reserved0;
 } rfm_fit_report;
 
 int rfm_abi_version(void);

@@ -31,7 +31,7 @@ def lib():
     return _lib
 
 
-def default_geometry(n_users, n_items, n_rows, n_segments, factors=64, stripes=True, window_factor=8.0, single_group=False):
+def default_geometry(n_users, n_items, n_rows, n_segments, factors=64, stripes=True, window_factor=8.0, single_group=False, segment_rows=None):
     """the launch geometry rfm_api.hip plans for a BPR problem without features on a 256-CU device (16 wavefronts of four 16-lane
     groups per workgroup): what DeviceSession.geometry() reports, restated so that the model runs without a GPU"""
     gpb, cus = 64, 256
@@ -41,7 +41,7 @@ def default_geometry(n_users, n_items, n_rows, n_segments, factors=64, stripes=T
     max_groups = max(1, min(n_rows // 128, min(n_users, n_items) // 3))
     working = min(grid * gpb, max_groups)
     g = dict(workgroups=grid, groups_per_workgroup=gpb, working_groups=working, units_per_launch=n_segments, n_units=n_segments,
-             stripe_rows=0, stripe_window=1, single_group=single_group, epoch_part=None, n_items=n_items)
+             stripe_rows=0, stripe_window=1, single_group=single_group, epoch_part=None, n_items=n_items, segment_rows=segment_rows)
     if stripes and min(n_rows // 128, min(n_users, n_items) // 3) >= 32 * 16 * 4:
         window = int(max(1, min(32, int(window_factor * n_items / working + 0.5))))
         rows = min(256, (156 * 1024 - 4 * (factors + 1)) // (4 * (1 + 2 * (factors + 1))), n_items)

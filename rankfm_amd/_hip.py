@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankfm_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK = 0
 ERR_BAD_ARG, ERR_UNKNOWN_SCHEDULE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_USER_SATURATED, ERR_WORKSPACE = (
     -1, -2, -3, -4, -5, -6, -7)
@@ -59,12 +59,13 @@ class FitReport(C.Structure):
         ("plan_token", C.c_int64),
         ("workgroups", C.c_int32), ("groups_per_workgroup", C.c_int32), ("working_groups", C.c_int64),
         ("units_per_launch", C.c_int64), ("n_units", C.c_int64), ("stripe_rows", C.c_int32), ("stripe_window", C.c_int32),
+        ("segment_rows", C.c_int32), ("reserved0", C.c_int32),
     ]
 
     def geometry(self):
         """launch geometry as a dict (rankfm_amd.order mirrors the engine's negative draws from it)"""
         return {k: int(getattr(self, k)) for k in ("workgroups", "groups_per_workgroup", "working_groups", "units_per_launch",
-                                                   "n_units", "stripe_rows", "stripe_window", "launches_per_epoch")}
+                                                   "n_units", "stripe_rows", "stripe_window", "launches_per_epoch", "segment_rows")}
 
 
 class ModelView(C.Structure):

@@ -177,7 +177,7 @@ __global__ void sw_to_csr_kernel(const int32_t *__restrict__ interactions, const
 struct Workspace {
     float *pos_scale;             // [I]     persistent across calls (plan_is_cached)
     float *sw_csr;                // [N]     persistent
-    int4 *seg_desc;               // [<= U + N / kSegmentRows]  persistent
+    int4 *seg_desc;               // [<= U + N / kStripeSegmentRows]  persistent
     int32_t *hot_item;            // [kMaxHot] persistent
     int32_t *hot_period;          // [kMaxHot] persistent
     unsigned int *sw_max_bits;    // bits of max |sample_weight| (persistent, written with the plan)
@@ -199,7 +199,8 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 constexpr int kMaxHot = 64;                      // hot-row accumulator slots per workgroup (LDS: kMaxHot * (F + 2) floats)
 
-static size_t max_segments(int64_t n_rows, int n_users) { return (size_t)n_users + (size_t)(n_rows / kSegmentRows) + 1; }
+constexpr int kStripeSegmentRows = 16;         // segments of a plan that uses negative stripes (see rfm_fit_device, "segment length")
+static size_t max_segments(int64_t n_rows, int n_users) { return (size_t)n_users + (size_t)(n_rows / kStripeSegmentRows) + 1; }
 
 static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_feat_tab, int n_factors) {
     Workspace w;
@@ -351,18 +352,35 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         RFM_HIP(hipMemcpyAsync(ws.mt_state, mt.data(), 625 * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     }
     // (skipped when the caller vouches for a cached plan: the lists were checked when it was built)
-    if (cfg->plan_token <= 0)
+    if (cfg->plan_token <= 0)      // (a cached plan of either kind: the lists were checked when it was built)
         degree_check_kernel<<<dim3((cfg->n_users + 255) / 256), dim3(256), 0, stream>>>(b->csr_offsets, b->csr_items, cfg->n_users,
                                                                                           cfg->n_items, ws.error_flags);
 
     // ---- plan, part 1 (segments kernel): user segments.  A user of degree d is cut into ceil(d / 32) near-equal runs of
     //      consecutive CSR positions; descriptors {user, first position, length} are built on the host from the offsets.
     //      The plan lives in the persistent head of the workspace; `plan_token` (= segment count) says it is still valid.
-    // plan_token = segment count | hot-slot count << 40
-    const bool have_plan = cfg->plan_token > 0 && cfg->plan_token != kRowsPlan;
+    // Segment length.  With negative stripes a user's segment should span several (workgroup, window) slots: all negatives of the
+    // rows inside one slot come from the same ~190 items, and what a user is contrasted with inside an epoch is what the ranking
+    // quality depends on (CPU model, profiles/r02_notes.md: 32-row segments cost ~1.3 points of hit_rate@10 at 30,000 x 12,000 even
+    // in the SEQUENTIAL algorithm, 16-row segments 0.3).  So the plan is cut into 16-row segments when stripes are going to be
+    // used -- decided here, before the plan, from everything the later `use_stripes` depends on except the plan itself.
+    const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
+    const bool one_group_flag = (cfg->debug_flags & 1) != 0;
+    bool want_stripes = use_segments && !feat && !(cfg->debug_flags & 8) && !getenv("RFM_NO_STRIPES") &&
+                        (cfg->max_samples == 1 || getenv("RFM_WARP_STRIPES")) && cfg->n_factors == shape->group * shape->kpl &&
+                        (one_group_flag || (damp_m > 0.0f && N > 0));
+    if (want_stripes && !one_group_flag && cfg->n_workgroups <= 0) {
+        const long long cap_groups = std::min<long long>(N / 128, (long long)std::min(cfg->n_users, cfg->n_items) / 3);
+        if (cap_groups < 32LL * 16 * (64 / shape->group)) want_stripes = false;
+    }
+    int seg_rows = want_stripes ? kStripeSegmentRows : kSegmentRows;
+    if (getenv("RFM_SEGMENT_ROWS")) seg_rows = std::max(1, std::min(kSegmentRows, atoi(getenv("RFM_SEGMENT_ROWS"))));   // (experiment knob)
+    // plan_token = segment count | hot-slot count << 40 | segment length << 48; a plan cut for another segment length is rebuilt
+    const bool token_plan = cfg->plan_token > 0 && cfg->plan_token != kRowsPlan;
+    const bool have_plan = token_plan && (int)((cfg->plan_token >> 48) & 0xFF) == seg_rows;
     int64_t n_segments = have_plan ? (cfg->plan_token & (((int64_t)1 << 40) - 1)) : 0;
-    int n_hot = have_plan ? (int)(cfg->plan_token >> 40) : 0;
-    const bool build_plan = !serial && cfg->plan_token <= 0;
+    int n_hot = have_plan ? (int)((cfg->plan_token >> 40) & 0xFF) : 0;
+    const bool build_plan = !serial && (cfg->plan_token <= 0 || (token_plan && !have_plan));
     std::vector<int64_t> off;
     if (use_segments && build_plan) {
         off.resize((size_t)cfg->n_users + 1);
@@ -376,7 +394,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         for (int u = 0; u < cfg->n_users; ++u) {
             const int64_t d = off[u + 1] - off[u];
             if (d <= 0) continue;
-            const int64_t parts = (d + kSegmentRows - 1) / kSegmentRows;
+            const int64_t parts = (d + seg_rows - 1) / seg_rows;
             for (int64_t p = 0; p < parts; ++p) {
                 const int64_t s0 = off[u] + d * p / parts, s1 = off[u] + d * (p + 1) / parts;
                 desc.push_back(make_int4(u, (int)s0, (int)(s1 - s0), 0));
@@ -398,8 +416,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
                                                                                               cfg->n_items, ws.error_flags);
         }
     }
-    const bool single_group = use_segments && (cfg->debug_flags & 1) != 0, fresh = (cfg->debug_flags & 2) != 0;
-    const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
+    const bool single_group = use_segments && one_group_flag, fresh = (cfg->debug_flags & 2) != 0;
     const bool damp = !serial && !single_group && damp_m > 0.0f && N > 0;
 
     // ---- plan, part 2: item popularity (positive occurrences per item), needed by the damping and by the hot-row choice
@@ -435,17 +452,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // RFM_WARP_STRIPES=1 switches them on for experiments.
     // Full factor rows only (n_factors == lanes per group x dwords per lane: 16, 32, 48, 64, 96, 128, ...): the stripe
     // instantiations carry no per-dword bounds predicate.
-    bool use_stripes = use_segments && !feat && !(cfg->debug_flags & 8) && !getenv("RFM_NO_STRIPES") &&
-                       (cfg->max_samples == 1 || getenv("RFM_WARP_STRIPES")) && cfg->n_factors == shape->group * shape->kpl &&
-                       (damp || single_group);     // undamped Hogwild on skewed data needs every push published at once (notes)
-    // ... for launches that fill a good part of the chip: a few workgroups are nowhere near the atomic ceiling (their time is
-    // memory latency), and delayed publication only costs them accuracy.  (One group alone keeps the stripes: that is the
-    // sequential form of the production kernel the parity tests pin to the oracle.)  The grid is not known yet; estimate it
-    // from the same caps the geometry below applies.
-    if (use_stripes && !single_group && cfg->n_workgroups <= 0) {
-        const long long cap_groups = std::min<long long>(N / 128, (long long)std::min(cfg->n_users, cfg->n_items) / 3);
-        if (cap_groups < 32LL * 16 * (64 / shape->group)) use_stripes = false;
-    }
+    // (decided before the plan was cut -- `want_stripes`, "Segment length" above -- including the size condition: launches that
+    // do not fill a good part of the chip are nowhere near the atomic ceiling, their time is memory latency, and delayed
+    // publication only costs them accuracy; one group alone keeps the stripes: that is the sequential form of the production
+    // kernel the parity tests pin to the oracle.  Undamped Hogwild on skewed data needs every push published at once: notes.)
+    const bool use_stripes = want_stripes && use_segments;
     const sgd_launch_fn launch = use_stripes ? shape->table()[10 + (fresh ? 1 : 0) + (use_hot ? 2 : 0)]
                                  : use_hot  ? shape->table()[8 + (fresh ? 1 : 0)]
                                  : use_segments ? shape->table()[4 + (feat ? 1 : 0) + (fresh ? 2 : 0)]
@@ -746,7 +757,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->n_units = units;
         rep->stripe_rows = stripe_rows;
         rep->stripe_window = stripe_window;
-        rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40)) : kRowsPlan);
+        rep->segment_rows = use_segments ? seg_rows : 0;
+        rep->reserved0 = 0;
+        rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40) | ((int64_t)seg_rows << 48)) : kRowsPlan);
     }
     return status;
 }

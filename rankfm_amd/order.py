@@ -51,11 +51,13 @@ def perm(pos, n, bits, key):
     return x.astype(np.int64)
 
 
-def segments(csr_offsets):
-    """(user, first CSR position, length) of every segment, in the planner's enumeration order"""
+def segments(csr_offsets, rows=None):
+    """(user, first CSR position, length) of every segment, in the planner's enumeration order; `rows` = longest segment of the
+    plan (rfm_fit_report.segment_rows; SEGMENT_ROWS when not given)"""
+    rows = int(rows or SEGMENT_ROWS)
     off = np.asarray(csr_offsets, dtype=np.int64)
     deg = np.diff(off)
-    parts = (deg + SEGMENT_ROWS - 1) // SEGMENT_ROWS
+    parts = (deg + rows - 1) // rows
     users = np.repeat(np.arange(len(deg), dtype=np.int64), parts)
     p = np.arange(parts.sum(), dtype=np.int64) - np.repeat(np.cumsum(parts) - parts, parts)
     d, n = deg[users], parts[users]
@@ -64,15 +66,15 @@ def segments(csr_offsets):
     return users, s0, s1 - s0
 
 
-def epoch_positions(csr_offsets, seed, epoch):
+def epoch_positions(csr_offsets, seed, epoch, segment_rows=None):
     """CSR positions in the order the segments kernel visits them in `epoch` (single-group / sequential order)"""
-    return _visit(csr_offsets, seed, epoch)[0]
+    return _visit(csr_offsets, seed, epoch, segment_rows)[0]
 
 
-def _visit(csr_offsets, seed, epoch):
+def _visit(csr_offsets, seed, epoch, segment_rows=None):
     """per visited row, in the sequential (segment order, then within-segment) enumeration of `epoch_positions`:
     (CSR position, segment-order position sp of its segment, index t inside the segment), and the segment lengths by sp"""
-    users, begin, length = segments(csr_offsets)
+    users, begin, length = segments(csr_offsets, segment_rows)
     S = len(users)
     ek = epoch_key(seed, epoch)
     seg_order = perm(np.arange(S), S, perm_bits(S), ek ^ 0x5bd1e995)
@@ -91,7 +93,7 @@ def row_schedule(csr_offsets, seed, epoch, geometry):
     sgd_segments_kernel -- the row group that processes it (`group`: group g of a launch walks the segments at order positions
     p0 + g, p0 + g + n_groups, ...), the iteration of that group's loop at which it does (`it`: rows the group has done in the
     launch before), its workgroup and launch; plus `seg_len` by sp and the epoch key."""
-    pos, sp, t, seg_len, ek = _visit(csr_offsets, seed, epoch)
+    pos, sp, t, seg_len, ek = _visit(csr_offsets, seed, epoch, geometry.get("segment_rows"))
     S = len(seg_len)
     single = bool(geometry["single_group"])
     n_groups = 1 if single else int(geometry["working_groups"])

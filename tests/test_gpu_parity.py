@@ -91,7 +91,8 @@ def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1,
     pairs_csr = np.ascontiguousarray(pairs[by_csr])
     assert np.array_equal(pairs_csr[:, 1], csr.items)
     sw_csr = np.ascontiguousarray(sw[by_csr])
-    perms = np.stack([order.epoch_positions(csr.offsets, seed, e) for e in range(epochs)]).astype(np.int32)
+    seg_rows = (geometry or {}).get("segment_rows") or None          # the plan's segment length (16 with negative stripes)
+    perms = np.stack([order.epoch_positions(csr.offsets, seed, e, seg_rows) for e in range(epochs)]).astype(np.int32)
     o = {k: v.copy() for k, v in w0.items()}
     out = oracle.fit(pairs_csr, sw_csr, csr.offsets, csr.items, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"],
                      o["v_if"], 0.01, 0.1, lr, schedule, 0.25, max_samples, epochs, perms=perms, rng_mode=oracle.RNG_COUNTER,

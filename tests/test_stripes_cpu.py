@@ -116,3 +116,17 @@ def test_saturated_stripe_falls_back_to_the_catalogue(oracle):
     by_csr = np.lexsort((pairs[:, 1], pairs[:, 0]))
     users_csr = pairs[by_csr][:, 0][visit]
     assert np.all(neg[users_csr == 0] >= 56) and np.isfinite(out["ll"]).all()
+
+
+def test_segments_follow_the_plans_segment_length():
+    """rfm_fit_report.segment_rows: a plan that uses negative stripes cuts 16-row segments (a user's rows then span several
+    stripes); the host mirror must cut the same ones"""
+    from rankfm_amd import order, synthetic
+    pairs, csr = synthetic.make_interactions(300, 200, 12000, seed=4)
+    for rows in (32, 16, 8):
+        users, begin, length = order.segments(csr.offsets, rows)
+        assert length.max() <= rows and length.min() >= 1 and length.sum() == 12000
+        deg = np.diff(csr.offsets)
+        assert len(users) == int(((deg + rows - 1) // rows).sum())
+        assert np.array_equal(np.sort(order.epoch_positions(csr.offsets, 3, 0, rows)), np.arange(12000))
+    assert np.array_equal(order.epoch_positions(csr.offsets, 3, 0), order.epoch_positions(csr.offsets, 3, 0, 32))

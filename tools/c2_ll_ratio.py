@@ -68,7 +68,7 @@ for spec in (sys.argv[1:] or ["0:0"]):
         from rankfm_amd import order
         pos_step, user_step = step_scales(sess, float(damping))
         by_csr = np.lexsort((pairs[:, 1], pairs[:, 0]))
-        perms = np.stack([order.epoch_positions(csr.offsets, 1492, e) for e in range(2)]).astype(np.int32)
+        perms = np.stack([order.epoch_positions(csr.offsets, 1492, e, geo.get("segment_rows") or None) for e in range(2)]).astype(np.int32)
         d = {k: v.copy() for k, v in synthetic.init_weights(U, I, F, seed=1492).items()}
         outd = orc.fit(np.ascontiguousarray(pairs[by_csr]), np.ascontiguousarray(sw[by_csr]), csr.offsets, csr.items, x_uf, x_if,
                        d["w_i"], d["w_if"], d["v_u"], d["v_i"], d["v_uf"], d["v_if"], 0.01, 0.1, 0.1, "constant", 0.25, 1, 2,
