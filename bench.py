@@ -14,7 +14,9 @@ resident in HBM when the timed region starts.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus:
   roofline     achieved = algorithmic bytes (24F+32 = 1568 B per update) x rows per launch / average
-               HIP-event duration of the SGD kernel launch, against the 8 TB/s HBM3E peak
+               HIP-event duration of the SGD kernel launch, against the 8 TB/s HBM3E peak; `peak_measured` = what a plain
+               streaming kernel gets from this box's HBM (rfm_hbm_probe), `frac_whole_catalogue` = the same fraction for the
+               kernel with the reference's sampler (every negative drawn from the whole catalogue, no negative stripes)
   cpu_baseline the CPU restatement of the reference's `_fit` (oracle/, "port"; MT19937 + linear membership scan like
                the reference) timed on ONE host core (the reference is single-threaded) on a bounded sample
 """
@@ -93,6 +95,7 @@ def main():
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
     ap.add_argument("--weak", action="store_true", help="configs 4 / 5: weak scaling (every rank its own config-sized shard)")
     ap.add_argument("--learning-rate", type=float, default=0.0, help="override the config's learning rate")
+    ap.add_argument("--tune", default="", help="geometry overrides of rfm_fit_config (experiments): 'stripe_window=12,segment_rows=32'")
     args = ap.parse_args()
 
     import torch
@@ -160,7 +163,8 @@ def main():
     trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
                                         syncs_per_epoch=args.syncs_per_epoch, seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
                                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
-                                        shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check)
+                                        shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check,
+                                        tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv})
     broadcast_from_rank0([trainer.shared.flat])
 
     def barrier():
@@ -211,14 +215,43 @@ def main():
                     "interactions, all items)" % (args.config, 0 if world == 1 else rank, world if world > 1 else max(args.share, 1), U, I, cfg["n_interactions"], u_local, n_local))
         else:
             what = "%s: synthetic %d users x %d items x %d interactions per GPU" % (args.config, U, I, N)
+        # which sampler the timed kernel used: the reference draws every negative uniformly over the catalogue
+        # (rankfm/_rankfm.pyx:250-253); large BPR launches draw a window's negatives from a stripe of items held in LDS
+        geo = sess.geometry() if sess is not None else {}
+        if geo.get("stripe_rows", 0) > 0:
+            sampler = ("negative stripes: each workgroup draws the negatives of a window of %d rows per row group from %d items held in LDS "
+                       "(stripes tile a keyed permutation of the catalogue, every item offered equally often), user segments <= %d rows"
+                       % (geo["stripe_window"], geo["stripe_rows"], geo.get("segment_rows", 32)))
+        else:
+            sampler = "negatives drawn uniformly over the whole catalogue (the reference's sampler), user segments <= %d rows" % (geo.get("segment_rows") or 32)
+        peak_measured = frac_whole = k_ms_whole = None
+        if world == 1:
+            import ctypes as C
+            from rankfm_amd import _hip
+            rd, cp = C.c_double(0.0), C.c_double(0.0)
+            if _hip.lib().rfm_hbm_probe(C.c_size_t(2 << 30), 5, C.byref(rd), C.byref(cp)) == 0:
+                peak_measured = {"read": rd.value, "copy": cp.value, "unit": "GB/s",
+                                 "how": "rfm_hbm_probe: 16 B/lane streaming kernel over 2 GiB, best of 5 launches (copy = read + write bytes)"}
+            if geo.get("stripe_rows", 0) > 0:
+                # the same workload with the reference's sampler (debug_flags bit 3): continues from the trained weights
+                from rankfm_amd.engine import DeviceSession
+                plain = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"], shard["x_uf"], x_if,
+                                      {k: v.clone() for k, v in sess.weights.items()}, device=device, seed=1492, debug_flags=args.debug_flags | 8,
+                                      hogwild_damping=args.damping, check_finite=not args.no_check, **hyper)
+                plain.run(epochs=2, epoch_begin=epoch)
+                k_ms_whole = float(np.mean(plain.run(epochs=5, epoch_begin=epoch + 2)["sgd_kernel_ms"]))
+                frac_whole = bytes_per_update * N / (k_ms_whole * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                del plain
         out = {
             "metric": "(user,item,neg) pairwise updates/sec at k=64; achieved HBM GB/s vs peak",
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, factors=%d, loss=%s%s%s, learning_rate=%g, zipf_s=%g, hogwild fp32 atomics, counter RNG"
+            "config": {"workload": "%s, factors=%d, loss=%s%s%s, learning_rate=%g, zipf_s=%g, hogwild fp32 atomics, counter RNG, %s"
                                    % (what, F, cfg["loss"], " max_samples=%d" % cfg["max_samples"] if cfg["max_samples"] > 1 else "",
-                                      ", %d + %d dense user/item features" % (n_uf, n_if) if n_uf or n_if else "", lr, args.zipf),
+                                      ", %d + %d dense user/item features" % (n_uf, n_if) if n_uf or n_if else "", lr, args.zipf, sampler),
+                       "sampler": {"stripe_rows": geo.get("stripe_rows", 0), "stripe_window": geo.get("stripe_window", 0),
+                                   "segment_rows": geo.get("segment_rows", 0), "workgroups": geo.get("workgroups", 0)},
                        "n_users_total": u_local * world, "n_interactions_total": n_job, "parallelism": "user-shard dp%d" % world,
                        "rccl_ranks_seen": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
                        "collective_backend": dist.get_backend() if world > 1 else None,
@@ -226,6 +259,8 @@ def main():
                        "mean_draws_per_update": mean_draws, "final_mean_ll_per_update": ll_last / N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "peak_measured": peak_measured,
+                         "frac_whole_catalogue": frac_whole, "kernel_ms_whole_catalogue": k_ms_whole,
                          "kernel": "rfm::sgd_features_kernel" if (n_uf or n_if) else "rfm::sgd_segments_kernel", "kernel_ms_per_launch": k_ms,
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }

@@ -103,13 +103,25 @@ typedef struct rfm_fit_config {
     int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
                                       bit 1: factor-row loads bypass the per-CU L1,
                                       bit 2: no LDS accumulation of hot item rows,
-                                      bit 3: no negative stripes (draws over the whole catalogue, atomics per negative) */
+                                      bit 3: no negative stripes (draws over the whole catalogue, atomics per negative),
+                                      bit 4: negative stripes for WARP as well (experiments; BPR only by default) */
     int32_t epoch_part_index;      /* with epoch_parts > 1: run only part k (0-based) of each epoch's visiting order -- lets a */
     int32_t epoch_parts;           /* multi-GPU caller exchange item deltas several times per epoch; 0 or 1 = whole epochs    */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
                                       scales) into the head of `workspace`; > 0: the value rfm_fit_report.plan_token returned
                                       by an earlier call on the SAME workspace, interactions, geometry and damping -- the
                                       plan is reused and the planning pass is skipped */
+    /* Geometry overrides of the Hogwild plan, 0 = automatic (what production uses).  They exist so that experiments and the
+     * parity tools steer the engine through THIS struct and nothing else: the library reads no environment variable, and the
+     * host mirror (rankfm_amd/order.py) sees the effective values in rfm_fit_report. */
+    int32_t tune_segment_rows;     /* longest user segment, 1..32 (auto: 32, 16 for plans that use negative stripes) */
+    int32_t tune_stripe_window;    /* rows per group between stripe changes (auto: 8 I / groups, at most 32) */
+    int32_t tune_stripe_rows;      /* items per stripe (auto: groups x window / 2, at most what LDS holds); -1 = none: the pipelined
+                                      row loop of the stripe kernel with whole-catalogue draws */
+    int32_t tune_hot_publications; /* publications of a hot row per epoch and workgroup (auto: 48) */
+    int32_t tune_feature_waves;    /* wavefronts per workgroup of the features kernel, 2..16 (auto: 16) */
+    int32_t tune_table_every;      /* features kernel: every k-th row of a group hands its step to the table trainer (auto: 8) */
+    int32_t tune_reserved[2];      /* must be 0 */
 } rfm_fit_config;
 
 /* All pointers of one struct live in the same memory space: device memory for the *_device entry
@@ -161,6 +173,11 @@ const char *rfm_last_error(void);            /* text of the last RFM_ERR_HIP on 
 int rfm_device_count(void);                  /* number of gfx950 devices visible, 0 if none */
 int rfm_fit_supported(const rfm_fit_config *cfg);          /* RFM_OK or the error rfm_fit_* would return */
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg); /* 0 on a bad config */
+
+/* Measurement aid (bench.py `roofline.peak_measured`): the rate at which this box's HBM serves a plain streaming kernel over
+ * `bytes` of device memory -- a read-only pass and a copy (read + write), best of `iters` launches each, in GB/s.  The SGD
+ * path's roofline is quoted against the 8 TB/s data-sheet peak AND against this achievable figure. */
+int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps);
 
 /* `_fit` on buffers already resident in HBM.  Work is enqueued on `hip_stream` (a hipStream_t; NULL =
  * the default stream); the call returns after one stream synchronisation at the end, when the report

@@ -36,7 +36,24 @@ class FitConfig(C.Structure):
         ("debug_update_mode", C.c_int32), ("debug_shape", C.c_int32), ("debug_flags", C.c_int32),
         ("epoch_part_index", C.c_int32), ("epoch_parts", C.c_int32),
         ("plan_token", C.c_int64),
+        ("tune_segment_rows", C.c_int32), ("tune_stripe_window", C.c_int32), ("tune_stripe_rows", C.c_int32),
+        ("tune_hot_publications", C.c_int32), ("tune_feature_waves", C.c_int32), ("tune_table_every", C.c_int32),
+        ("tune_reserved", C.c_int32 * 2),
     ]
+
+
+#: names of the geometry overrides of rfm_fit_config (0 = automatic); EngineOptions.tune / DeviceSession(tune=...) carry them
+TUNE_FIELDS = ("segment_rows", "stripe_window", "stripe_rows", "hot_publications", "feature_waves", "table_every")
+
+
+def tune_kwargs(tune):
+    """{'stripe_window': 12, ...} -> FitConfig keyword arguments (unknown names raise)"""
+    out = {}
+    for k, v in (tune or {}).items():
+        if k not in TUNE_FIELDS:
+            raise ValueError("unknown geometry override %r (known: %s)" % (k, ", ".join(TUNE_FIELDS)))
+        out["tune_" + k] = int(v)
+    return out
 
 
 class FitBuffers(C.Structure):
@@ -82,7 +99,7 @@ class ModelView(C.Structure):
 EXPORTS = (
     "rfm_abi_version", "rfm_status_string", "rfm_last_error", "rfm_device_count", "rfm_fit_supported",
     "rfm_fit_workspace_bytes", "rfm_fit_device", "rfm_fit_host", "rfm_predict_device", "rfm_predict_host",
-    "rfm_recommend_device", "rfm_recommend_workspace_bytes", "rfm_recommend_host", "rfm_similar_host",
+    "rfm_recommend_device", "rfm_recommend_workspace_bytes", "rfm_recommend_host", "rfm_similar_host", "rfm_hbm_probe",
 )
 
 _lib = None
@@ -137,6 +154,8 @@ def lib():
     L.rfm_recommend_host.restype = C.c_int
     L.rfm_recommend_host.argtypes = [C.POINTER(ModelView), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_int32, C.c_void_p, C.c_int]
+    L.rfm_hbm_probe.restype = C.c_int
+    L.rfm_hbm_probe.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rfm_similar_host.restype = C.c_int
     L.rfm_similar_host.argtypes = [C.POINTER(ModelView), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
     if L.rfm_abi_version() != ABI_VERSION:

@@ -13,7 +13,7 @@ Engine behaviour that the reference cannot express is carried by `EngineOptions`
 import ctypes as C
 import os
 from collections.abc import Mapping
-from dataclasses import dataclass, replace
+from dataclasses import dataclass, field, replace
 from typing import Optional
 
 import numpy as np
@@ -48,6 +48,7 @@ class EngineOptions:
                                    # and publish their updates once per window: ~25 % faster, measured cost
                                    # ~0.6 point of hit_rate@10 at 30,000 x 12,000; False = whole-catalogue draws (debug_flags bit 3)
     debug_flags: int = 0          # include/rankfm_hip.h: bit 0 = Hogwild kernel on one row group, bit 1 = L1-bypassing loads
+    tune: dict = field(default_factory=dict)   # geometry overrides of rfm_fit_config (_hip.TUNE_FIELDS), experiments only
 
     def validated(self):
         if self.mode not in ("hogwild", "serial"):
@@ -207,7 +208,8 @@ def _fit(interactions, sample_weight, user_items, x_uf, x_if, w_i, w_if, v_u, v_
         rng=_hip.RNG_MT19937 if opt.rng == "mt19937" else _hip.RNG_COUNTER, seed=seed & 0xFFFFFFFF,
         check_finite=int(opt.check_finite), want_penalty=int(bool(verbose) or report is not None),
         n_workgroups=int(opt.n_workgroups), rows_per_launch=int(opt.rows_per_launch),
-        hogwild_damping=float(opt.damping), debug_flags=int(opt.debug_flags) | (0 if opt.negative_stripes else 8))
+        hogwild_damping=float(opt.damping), debug_flags=int(opt.debug_flags) | (0 if opt.negative_stripes else 8),
+        **_hip.tune_kwargs(opt.tune))
     buf = _hip.FitBuffers(
         interactions=_ptr(interactions), sample_weight=_ptr(sample_weight),
         csr_offsets=_ptr(csr.offsets), csr_items=_ptr(csr.items), x_uf=_ptr(x_uf), x_if=_ptr(x_if),

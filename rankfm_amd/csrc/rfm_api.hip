@@ -243,6 +243,9 @@ static int validate(const rfm_fit_config *c) {
     if (c->learning_schedule != RFM_SCHEDULE_CONSTANT && c->learning_schedule != RFM_SCHEDULE_INVSCALING)
         return RFM_ERR_UNKNOWN_SCHEDULE;
     if (c->mode != RFM_MODE_HOGWILD && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;
+    if (c->tune_segment_rows < 0 || c->tune_segment_rows > kSegmentRows || c->tune_stripe_window < 0 || c->tune_stripe_rows < -1 ||
+        c->tune_hot_publications < 0 || c->tune_feature_waves < 0 || c->tune_table_every < 0 || c->tune_reserved[0] || c->tune_reserved[1])
+        return RFM_ERR_BAD_ARG;
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
     if (c->rng == RFM_RNG_MT19937 && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;   // one serial stream
     if (!pick_shape(c->n_factors)) return RFM_ERR_UNSUPPORTED;
@@ -262,6 +265,28 @@ static int device_ok() {
     }
     g_sm_count = prop.multiProcessorCount;
     return RFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HBM stream probe (rfm_hbm_probe): what this box's memory system delivers to a plain streaming kernel, measured next to the
+// SGD kernel so that the roofline fraction can also be read against an ACHIEVABLE peak, not only the 8 TB/s of the data sheet
+// ---------------------------------------------------------------------------------------------
+template <bool COPY>
+__global__ void __launch_bounds__(256) stream_probe_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4, float *sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.0f;
+    // four independent 16-byte accesses per lane in flight
+    for (; idx + 3 * stride < n4; idx += 4 * stride) {
+        const float4 a = src[idx], b = src[idx + stride], c = src[idx + 2 * stride], d = src[idx + 3 * stride];
+        if (COPY) { dst[idx] = a; dst[idx + stride] = b; dst[idx + 2 * stride] = c; dst[idx + 3 * stride] = d; }
+        else acc += (a.x + b.y) + (c.z + d.w);
+    }
+    for (; idx < n4; idx += stride) {
+        const float4 a = src[idx];
+        if (COPY) dst[idx] = a; else acc += a.x;
+    }
+    if (!COPY && acc == 123456.789f) *sink = acc;        // keeps the loads alive
 }
 
 }  // namespace rfm
@@ -306,6 +331,44 @@ int rfm_device_count(void) {
 }
 
 int rfm_fit_supported(const rfm_fit_config *cfg) { return validate(cfg); }
+
+int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps) {
+    int rc = device_ok();
+    if (rc != RFM_OK) return rc;
+    if (bytes < (1u << 20) || iters < 1) return RFM_ERR_BAD_ARG;
+    const size_t n4 = bytes / sizeof(float4);
+    float4 *src = nullptr, *dst = nullptr;
+    float *sink = nullptr;
+    struct Free { float4 *&a, *&b; float *&c; ~Free() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(c); } } guard{src, dst, sink};
+    RFM_HIP(hipMalloc((void **)&src, n4 * sizeof(float4)));
+    RFM_HIP(hipMalloc((void **)&dst, n4 * sizeof(float4)));
+    RFM_HIP(hipMalloc((void **)&sink, sizeof(float)));
+    RFM_HIP(hipMemset(src, 0, n4 * sizeof(float4)));
+    RFM_HIP(hipMemset(dst, 0, n4 * sizeof(float4)));
+    hipEvent_t e0, e1;
+    RFM_HIP(hipEventCreate(&e0));
+    RFM_HIP(hipEventCreate(&e1));
+    const int grid = (g_sm_count > 0 ? g_sm_count : 256) * 8;
+    double best[2] = {0.0, 0.0};
+    for (int mode = 0; mode < 2; ++mode) {
+        for (int it = 0; it < iters + 1; ++it) {            // (first pass untimed)
+            RFM_HIP(hipEventRecord(e0, nullptr));
+            if (mode == 0) stream_probe_kernel<false><<<dim3(grid), dim3(256), 0, nullptr>>>(src, dst, n4, sink);
+            else stream_probe_kernel<true><<<dim3(grid), dim3(256), 0, nullptr>>>(src, dst, n4, sink);
+            RFM_HIP(hipEventRecord(e1, nullptr));
+            RFM_HIP(hipEventSynchronize(e1));
+            float ms = 0.0f;
+            RFM_HIP(hipEventElapsedTime(&ms, e0, e1));
+            const double gbps = (double)(n4 * sizeof(float4)) * (mode == 0 ? 1.0 : 2.0) / ((double)ms * 1e-3) / 1e9;
+            if (it > 0 && gbps > best[mode]) best[mode] = gbps;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (read_gbps) *read_gbps = best[0];
+    if (copy_gbps) *copy_gbps = best[1];
+    return RFM_OK;
+}
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
@@ -366,15 +429,15 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // used -- decided here, before the plan, from everything the later `use_stripes` depends on except the plan itself.
     const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
     const bool one_group_flag = (cfg->debug_flags & 1) != 0;
-    bool want_stripes = use_segments && !feat && !(cfg->debug_flags & 8) && !getenv("RFM_NO_STRIPES") &&
-                        (cfg->max_samples == 1 || getenv("RFM_WARP_STRIPES")) && cfg->n_factors == shape->group * shape->kpl &&
+    bool want_stripes = use_segments && !feat && !(cfg->debug_flags & 8) &&
+                        (cfg->max_samples == 1 || (cfg->debug_flags & 16)) && cfg->n_factors == shape->group * shape->kpl &&
                         (one_group_flag || (damp_m > 0.0f && N > 0));
     if (want_stripes && !one_group_flag && cfg->n_workgroups <= 0) {
         const long long cap_groups = std::min<long long>(N / 128, (long long)std::min(cfg->n_users, cfg->n_items) / 3);
         if (cap_groups < 32LL * 16 * (64 / shape->group)) want_stripes = false;
     }
     int seg_rows = want_stripes ? kStripeSegmentRows : kSegmentRows;
-    if (getenv("RFM_SEGMENT_ROWS")) seg_rows = std::max(1, std::min(kSegmentRows, atoi(getenv("RFM_SEGMENT_ROWS"))));   // (experiment knob)
+    if (cfg->tune_segment_rows > 0) seg_rows = std::min(kSegmentRows, cfg->tune_segment_rows);
     // plan_token = segment count | hot-slot count << 40 | segment length << 48; a plan cut for another segment length is rebuilt
     const bool token_plan = cfg->plan_token > 0 && cfg->plan_token != kRowsPlan;
     const bool have_plan = token_plan && (int)((cfg->plan_token >> 48) & 0xFF) == seg_rows;
@@ -444,12 +507,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         n_hot = (int)hot_order.size();
     }
     const bool use_hot = use_segments && !feat && !single_group && n_hot > 0;
-    // Negative stripes (rfm_sgd.hpp, STRIPE; include/rfm_rng.h): the production path without features.  debug_flags bit 3 (or
-    // RFM_NO_STRIPES, an experiment knob) falls back to whole-catalogue draws with one set of atomics per negative.
+    // Negative stripes (rfm_sgd.hpp, STRIPE; include/rfm_rng.h): the production path without features.  debug_flags bit 3 falls back to whole-catalogue draws with one set of atomics per negative.
     // BPR only: WARP's candidate screening inside a stripe (up to 50 draws WITH replacement from ~200 items) changes the
     // statistics of the rank estimate -- against the sequential oracle the log-likelihood moved by -5 % at a 12-row window --
     // and the WARP instantiation gained no time from it (it is bound by its register spills, not by the candidate reads);
-    // RFM_WARP_STRIPES=1 switches them on for experiments.
+    // debug_flags bit 4 switches them on for experiments.
     // Full factor rows only (n_factors == lanes per group x dwords per lane: 16, 32, 48, 64, 96, 128, ...): the stripe
     // instantiations carry no per-dword bounds predicate.
     // (decided before the plan was cut -- `want_stripes`, "Segment length" above -- including the size condition: launches that
@@ -467,7 +529,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     const int groups_per_wave = serial ? 1 : 64 / shape->group;
     // features kernel: 16 wavefronts per workgroup share one LDS copy of the tables (<= 64 KB, checked above)
     int feat_waves = 16;
-    if (getenv("RFM_FEAT_WAVES")) feat_waves = std::max(2, std::min(16, atoi(getenv("RFM_FEAT_WAVES"))));   // (experiment knob)
+    if (cfg->tune_feature_waves > 0) feat_waves = std::max(2, std::min(16, cfg->tune_feature_waves));
     // (the table trainer also stages one step per row group: 1 + 2F + P + Q floats each; wide tables take smaller workgroups)
     while (feat_waves > 2 && sizeof(float) * (feat_table_floats(cfg) + (size_t)feat_waves * (64 / shape->group) *
                                               (1 + 2 * (size_t)cfg->n_factors + cfg->n_user_features + cfg->n_item_features)) > kLdsBytes)
@@ -542,12 +604,12 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         // sides; stripe = groups x window / 2 rows (<= 256): a smaller stripe would combine more pushes per publication but
         // concentrates the pending pushes on fewer rows, and the atomics no longer bound the kernel.
         const long long g_work = single_group ? 1 : std::min<long long>((long long)grid * gpb, max_groups > 0 ? max_groups : (1LL << 60));
-        stripe_window = (int)std::max<long long>(1, std::min<long long>(32, (long long)((getenv("RFM_STRIPE_FACTOR") ? atof(getenv("RFM_STRIPE_FACTOR")) : 8.0) * (double)cfg->n_items / (double)g_work + 0.5)));   // (RFM_STRIPE_FACTOR: experiment knob)
-        if (getenv("RFM_STRIPE_WINDOW")) stripe_window = std::max(1, atoi(getenv("RFM_STRIPE_WINDOW")));                     // (experiment knob)
+        stripe_window = (int)std::max<long long>(1, std::min<long long>(32, (long long)(8.0 * (double)cfg->n_items / (double)g_work + 0.5)));
+        if (cfg->tune_stripe_window > 0) stripe_window = cfg->tune_stripe_window;
         if (single_group) stripe_window = 1;      // one group alone: a fresh stripe for every row keeps it exactly sequential
-        const int combine = getenv("RFM_STRIPE_COMBINE") ? std::max(1, atoi(getenv("RFM_STRIPE_COMBINE"))) : 2;             // (experiment knob)
+        const int combine = 2;
         int want_rows = std::max(16, (int)std::min<long long>(g_work, gpb) * stripe_window / combine);
-        if (getenv("RFM_STRIPE_ROWS")) want_rows = std::max(0, atoi(getenv("RFM_STRIPE_ROWS")));                            // (experiment knob)
+        if (cfg->tune_stripe_rows != 0) want_rows = std::max(0, cfg->tune_stripe_rows);      // (-1: no stripe, pipelined row loop only)
         stripe_rows = std::max(want_rows > 0 ? 1 : 0, std::min(std::min(stripe_rows_cap, want_rows), cfg->n_items / (single_group ? 1 : grid)));
         // consecutive windows of one workgroup start grid x rows positions apart (include/rfm_rng.h): keep that step, taken
         // around the cycle of I positions, at least a stripe long so that they do not overlap
@@ -573,7 +635,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             scale[i] = n > damp_m ? (float)(damp_m / n) : 1.0f;
         }
         std::vector<int32_t> h_item(kMaxHot, 0), h_period(kMaxHot, 1);
-        const double hot_pubs = getenv("RFM_HOT_PUBS") ? atof(getenv("RFM_HOT_PUBS")) : 48.0;   // experiment knob
+        const double hot_pubs = cfg->tune_hot_publications > 0 ? (double)cfg->tune_hot_publications : 48.0;
         for (int s = 0; s < (use_hot ? n_hot : 0); ++s) {
             const int i = hot_order[s];
             // publish about 48 times per epoch and workgroup: ~2 % of the row's updates are pending chip-wide at any time

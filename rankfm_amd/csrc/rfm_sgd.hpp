@@ -332,6 +332,11 @@ struct RowStep {
     // workgroup); positive: published + expected pending sum.  Without the correction every pairwise utility is
     // overestimated by the positive's unseen downward pushes (log-likelihood -6 % against the sequential oracle at a 32-row
     // window on config 2; with it +0.1 %, profiles/r02_notes.md).
+    // The BIAS column of the sums receives every push of the window with the same sign (about -eta * sample weight * d_outer each,
+    // groups x window of them: 2048 at 64 groups x 32 rows, 6144 with 4-lane groups), which would wrap the +-128-unit range of the
+    // pending sums; it is therefore kept in a unit kSumCoarse times coarser (range +-8192 x the step scale; the factor columns are
+    // sums of signed terms ~100 times smaller and keep the fine unit).
+    static constexpr float kSumCoarse = 64.0f;
     lds_int *sn_sum = nullptr;
     float sn_inv_rows = 0.0f;
     int sn_rows = 0;
@@ -664,7 +669,7 @@ struct RowStep {
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
                     if (dword_ok(k)) vi[k] += (float)sn_sum[dword_f(k)] * c;
-                wi += (float)sn_sum[F] * c;
+                wi += (float)sn_sum[F] * (c * kSumCoarse);
             }
             float part = 0.0f;
 #pragma unroll
@@ -806,7 +811,8 @@ struct RowStep {
                 if (sub == 0) {
                     const int q = __float2int_rn(dwj * kHotScale);
                     __hip_atomic_fetch_add(sn_delta + jrow * (F + 1) + F, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(sn_sum + F, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(sn_sum + F, __float2int_rn(dwj * (kHotScale * (1.0f / kSumCoarse))), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             } else {
                 float *pv = a.v_i + (size_t)j * F + sub;
@@ -823,7 +829,7 @@ struct RowStep {
             else apply_f32<SERIAL>(a.w_i + (size_t)i * a.w_stride, wi, dwi);
             if (STRIPE && jrow >= 0) {
                 hot_add(sn_delta + jrow * (F + 1) + F, dwj);
-                hot_add(sn_sum + F, dwj);
+                hot_add(sn_sum + F, dwj * (1.0f / kSumCoarse));
             } else apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj);
         }
 

@@ -19,7 +19,7 @@ class DeviceSession:
                  learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25, max_samples=1,
                  mode="hogwild", rng="counter", seed=1492, device=None, n_workgroups=0, rows_per_launch=0,
                  check_finite=True, want_penalty=False, has_user_features=None, has_item_features=None,
-                 shape_override=0, hogwild_damping=0.0, debug_flags=0):
+                 shape_override=0, hogwild_damping=0.0, debug_flags=0, tune=None):
         if not torch.cuda.is_available():
             raise _hip.EngineUnavailable("no MI355X visible to PyTorch-ROCm: rankfm_amd has no CPU fallback")
         _hip.lib()
@@ -64,6 +64,7 @@ class DeviceSession:
         self.hogwild_damping = float(hogwild_damping)
         self._plan_token = 0
         self.debug_flags = int(debug_flags)
+        self.tune = _hip.tune_kwargs(tune)       # geometry overrides (experiments); part of the plan, so fixed per session
         self._geometry = None
 
     def _config(self, epochs, epoch_begin, part=None, rng_epoch_offset=0):
@@ -77,7 +78,7 @@ class DeviceSession:
             has_user_features=self.has_uf, has_item_features=self.has_if,
             epochs=int(epochs), epoch_begin=int(epoch_begin), mode=self.mode, rng=self.rng, seed=self.seed,
             check_finite=self.check_finite, want_penalty=self.want_penalty,
-            n_workgroups=self.n_workgroups, rows_per_launch=self.rows_per_launch, **self.hyper)
+            n_workgroups=self.n_workgroups, rows_per_launch=self.rows_per_launch, **self.tune, **self.hyper)
 
     def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True, part=None, rng_epoch_offset=0):
         """train `epochs` epochs in place on the resident tensors; returns the per-epoch report (numpy arrays)"""

@@ -186,6 +186,10 @@ def api_case(name, *, loss, with_features, str_ids, seed=5):
     rec_users = list(uid[:12]) + [unknown_u]
     rec_all = m2.recommend(rec_users, n_items=7, filter_previous=False, cold_start="nan")
     rec_new = m2.recommend(rec_users, n_items=7, filter_previous=True, cold_start="nan")
+    # similar_items / similar_users (rankfm/rankfm.py:405-454): the reference's own ranking for a few query rows
+    sim_item_q, sim_user_q = list(iid[[0, 3, 7, 11]]), list(uid[[0, 2, 5, 9]])
+    sim_items = np.stack([np.asarray(m2.similar_items(q, n_items=6)) for q in sim_item_q])
+    sim_users = np.stack([np.asarray(m2.similar_users(q, n_users=6)) for q in sim_user_q])
     out = dict(
         train_users=train.user_id.values.astype("U16" if str_ids else np.int64),
         train_items=train.item_id.values.astype("U16" if str_ids else np.int64),
@@ -202,6 +206,9 @@ def api_case(name, *, loss, with_features, str_ids, seed=5):
         rec_users=np.array(rec_users).astype("U16" if str_ids else np.int64),
         rec_all=rec_all.values.astype("U16" if str_ids else np.float64),
         rec_new=rec_new.values.astype("U16" if str_ids else np.float64),
+        sim_item_queries=np.array(sim_item_q).astype("U16" if str_ids else np.int64),
+        sim_user_queries=np.array(sim_user_q).astype("U16" if str_ids else np.int64),
+        sim_items=sim_items.astype("U16" if str_ids else np.int64), sim_users=sim_users.astype("U16" if str_ids else np.int64),
         hit_rate=np.float64(ref_eval.hit_rate(m2, test, k=7)),
         hit_rate_new=np.float64(ref_eval.hit_rate(m2, test, k=7, filter_previous=True)),
         reciprocal_rank=np.float64(ref_eval.reciprocal_rank(m2, test, k=7)),

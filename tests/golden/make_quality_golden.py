@@ -21,7 +21,7 @@ RankFM, _, ev = ref_loader.load_reference()
 out = {}
 for loss in ("bpr", "warp"):
     rows = []
-    for seed in (0, 1, 2):
+    for seed in range(5):
         d = synthetic.make_planted(seed=seed)
         train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
         m = RankFM(factors=20, loss=loss, max_samples=20)

@@ -29,7 +29,7 @@ def frames(d):
 
 if __name__ == "__main__":
     rows = []
-    for seed in (0, 1, 2):
+    for seed in range(5):
         d = synthetic.make_planted(seed=seed, **PROBLEM)
         train, test, uf, itf = frames(d)
         m = RankFM(factors=20, loss="bpr", learning_rate=LEARNING_RATE)

@@ -30,7 +30,7 @@ ap.add_argument("--sigma", type=float, default=0.1)
 ap.add_argument("--no-oracle", action="store_true")
 ap.add_argument("--debug-flags", default="0")
 ap.add_argument("--lr", type=float, default=0.1)
-ap.add_argument("--env", default="", help="variants of engine environment knobs: 'A=1,B=2;A=3' runs two variants")
+ap.add_argument("--variants", default="", help="geometry-override variants (rfm_fit_config tune_*): 'stripe_window=12,segment_rows=32;stripe_rows=-1'")
 a = ap.parse_args()
 U, I, N, F = a.users, a.items, a.rows, a.factors
 pairs, csr = synthetic.make_interactions(U, I, N, seed=0, zipf_s=a.zipf)
@@ -50,18 +50,14 @@ if not a.no_oracle:
                   0.01, 0.1, a.lr, "constant", 0.25, a.max_samples, a.epochs, perms=perms, rng_mode=orc.RNG_COUNTER, seed=1492,
                   membership="binary")
     print("oracle %.1fs ll/N %s  " % (time.time() - t0, out["ll"] / N) + " ".join("|%s| %.3f" % (k, np.linalg.norm(o[k])) for k in NAMES), flush=True)
-for envs in a.env.split(";"):
-  for kv in [x for x in envs.split(",") if x]:
-      if kv.split("=")[1] == "":
-          os.environ.pop(kv.split("=")[0], None)
-      else:
-          os.environ[kv.split("=")[0]] = kv.split("=")[1]
-  print("env", envs, flush=True)
+for envs in a.variants.split(";"):
+  tune = {x.split("=")[0]: int(x.split("=")[1]) for x in envs.split(",") if "=" in x}
+  print("variant", tune, flush=True)
   for wg in [int(x) for x in a.workgroups.split(",")]:
     for rpl in [int(x) for x in a.rows_per_launch.split(",")]:
           for m, fl in [(float(x), int(y)) for x in a.dampings.split(",") for y in a.debug_flags.split(",")]:
               sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=a.max_samples, seed=1492, learning_rate=a.lr,
-                                   hogwild_damping=m, n_workgroups=wg, rows_per_launch=rpl, debug_flags=fl)
+                                   hogwild_damping=m, n_workgroups=wg, rows_per_launch=rpl, debug_flags=fl, tune=tune)
               rep = sess.run(epochs=a.epochs, raise_on_error=False)
               g = sess.weights_to_host()
               line = "flags=%d " % fl + "wg=%4d rpl=%8d M=%6.1f st=%d launches=%d ms %s ll/N %s" % (wg, rpl, m, rep["status"], rep["launches_per_epoch"],

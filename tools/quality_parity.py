@@ -10,6 +10,8 @@ import numpy as np
 import pandas as pd
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _gpulock import gpu
 from oracle import oracle as orc
 from rankfm_amd import EngineOptions, RankFM, evaluation, synthetic
 
@@ -25,11 +27,18 @@ ap.add_argument("--tags", type=int, default=0)
 ap.add_argument("--schedule", default="constant")
 ap.add_argument("--workgroups", default="0")
 ap.add_argument("--dampings", default="0")
-ap.add_argument("--env", default="", help="variants of engine environment knobs for the GPU sides: 'A=1,B=2;A=' (empty value unsets)")
+ap.add_argument("--variants", default="", help="engine variants for the GPU sides, ';'-separated; a variant is a ','-separated list of "
+                "'nostripes' and geometry overrides (rfm_fit_config tune_*): e.g. ';nostripes;segment_rows=32;stripe_window=12,segment_rows=32'")
+ap.add_argument("--seed0", type=int, default=0)
 a = ap.parse_args()
 
 rows = []
-for seed in range(a.seeds):
+def engine_of(variant, **kw):
+    tune = {x.split("=")[0]: int(x.split("=")[1]) for x in variant.split(",") if "=" in x}
+    return EngineOptions(negative_stripes="nostripes" not in variant.split(","), tune=tune, **kw)
+
+
+for seed in range(a.seed0, a.seed0 + a.seeds):
     d = synthetic.make_planted(a.users, a.items, seed=seed, n_tags=a.tags)
     train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
     uf = itf = None
@@ -37,21 +46,16 @@ for seed in range(a.seeds):
         uf = pd.concat([pd.DataFrame({"u": np.arange(a.users)}), pd.DataFrame(d["user_tags"])], axis=1)
         itf = pd.concat([pd.DataFrame({"i": np.arange(a.items)}), pd.DataFrame(d["item_tags"])], axis=1)
     res = {}
-    sides = ["oracle"] + ["gpu:%s:%s:%s" % (w, m, e) for w in a.workgroups.split(",") for m in a.dampings.split(",") for e in a.env.split(";")]
+    sides = ["oracle"] + ["gpu:%s:%s:%s" % (w, m, e) for w in a.workgroups.split(",") for m in a.dampings.split(",") for e in a.variants.split(";")]
     for side in sides:
         wg, damp = (int(side.split(":")[1]), float(side.split(":")[2])) if side != "oracle" else (0, 0.0)
-        if side != "oracle":
-            for kv in [x for x in side.split(":", 3)[3].split(",") if x]:
-                if kv.split("=")[1] == "":
-                    os.environ.pop(kv.split("=")[0], None)
-                else:
-                    os.environ[kv.split("=")[0]] = kv.split("=")[1]
         m = RankFM(factors=a.factors, loss=a.loss, max_samples=a.max_samples, learning_schedule=a.schedule,
-                   engine=EngineOptions(seed=100 + seed, n_workgroups=wg, damping=damp))
+                   engine=engine_of(side.split(":", 3)[3] if side != "oracle" else "", seed=100 + seed, n_workgroups=wg, damping=damp))
         np.random.seed(seed)
         t0 = time.time()
         if side != "oracle":
-            m.fit(train, uf, itf, epochs=a.epochs)
+            with gpu():
+                m.fit(train, uf, itf, epochs=a.epochs)
         else:
             m._init_all(train, uf, itf, None)          # same initial weights (same numpy stream) as the GPU side
             ms = 1 if a.loss == "bpr" else a.max_samples
