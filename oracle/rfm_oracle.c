@@ -146,7 +146,7 @@ typedef struct {
     int32_t membership;              /* 0 linear (lsearch), 1 binary */
     int32_t stripe_rows;             /* counter mode with `row_stripe`: items per negative stripe (include/rfm_rng.h) */
     /* analysis only (NOT the reference's algorithm; 0 / 0 = the reference): the dense feature tables are updated on every
-     * `table_every`-th visited row only, with their step scaled by `table_step` -- a sequential stand-in for the engine's table
+     * `table_every`-th visited row only (never when it is negative), with their step scaled by `table_step` -- a sequential stand-in for the engine's table
      * trainer, which trains the tables on a sample of the rows while every row reads them (rfm_sgd.hpp, sgd_features_kernel) */
     int32_t table_every;
     float table_step;
@@ -258,7 +258,9 @@ static int fit_impl(const rfm_oracle_params *p,
             w_i[j] += eta * (sw * multiplier * (d_outer * -1.0f) - (d_reg_a * w_i[j]));   /* :280 */
 
             const float *xi = x_if + (size_t)i * Q, *xj = x_if + (size_t)j * Q, *xu = x_uf + (size_t)u * P;
-            const int do_tab = p->table_every <= 1 || r % p->table_every == 0;     /* (analysis option; always 1 for the reference) */
+            /* (analysis option; always 1 for the reference.  table_every < 0: the tables are frozen -- what the engine's row loop does
+             *  when its table trainer is switched off, debug_flags bit 5) */
+            const int do_tab = p->table_every < 0 ? 0 : (p->table_every <= 1 || r % p->table_every == 0);
             const float eta_t = p->table_step > 0.0f ? eta * p->table_step : eta;
             if (p->has_if && do_tab)                                               /* :283-286 */
                 for (int q = 0; q < Q; ++q) {

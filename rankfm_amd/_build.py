@@ -59,10 +59,12 @@ def build(force=False, verbose=False):
     if force and os.path.isdir(OBJ):
         shutil.rmtree(OBJ)
     os.makedirs(OBJ, exist_ok=True)
-    if not force and not _stale(LIB, srcs + _deps()):
-        return LIB
+    # every object is checked against its source and the shared headers (a partial RFM_BUILD_SHAPES build leaves the library newer
+    # than objects that are themselves out of date), then the library against the objects
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(_compile, srcs))
+    if not force and not _stale(LIB, objs):
+        return LIB
     subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
     if verbose:
         print("built", LIB)

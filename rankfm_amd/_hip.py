@@ -37,13 +37,13 @@ class FitConfig(C.Structure):
         ("epoch_part_index", C.c_int32), ("epoch_parts", C.c_int32),
         ("plan_token", C.c_int64),
         ("tune_segment_rows", C.c_int32), ("tune_stripe_window", C.c_int32), ("tune_stripe_rows", C.c_int32),
-        ("tune_hot_publications", C.c_int32), ("tune_feature_waves", C.c_int32), ("tune_table_every", C.c_int32),
+        ("tune_hot_publications", C.c_int32), ("tune_feature_waves", C.c_int32), ("tune_table_producers", C.c_int32),
         ("tune_reserved", C.c_int32 * 2),
     ]
 
 
 #: names of the geometry overrides of rfm_fit_config (0 = automatic); EngineOptions.tune / DeviceSession(tune=...) carry them
-TUNE_FIELDS = ("segment_rows", "stripe_window", "stripe_rows", "hot_publications", "feature_waves", "table_every")
+TUNE_FIELDS = ("segment_rows", "stripe_window", "stripe_rows", "hot_publications", "feature_waves", "table_producers")
 
 
 def tune_kwargs(tune):

@@ -181,6 +181,7 @@ struct Workspace {
     int32_t *hot_item;            // [kMaxHot] persistent
     int32_t *hot_period;          // [kMaxHot] persistent
     unsigned int *sw_max_bits;    // bits of max |sample_weight| (persistent, written with the plan)
+    float *feat_ring;             // features kernel: [2 * kFeatMaxProducers] batches of staged steps (never read before written)
     size_t volatile_offset;       // everything from here on is zeroed at the start of every call
     double *ll;                   // [epochs]
     unsigned long long *draws;    // [epochs]
@@ -191,7 +192,7 @@ struct Workspace {
     float *multiplier;            // [max_samples + 1]
     float *w_pad;                     // [n_items * kBiasStride] item biases, one 64-byte line each (SgdArgs::w_stride)
     float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: zero between launches
-    float *feat_snapshot;         // [(P+Q)*F + Q] feature tables at launch start (LDS-replica merge)
+    unsigned int *feat_flags;     // [kFeatFlagWords] producer / trainer hand-shake of the features kernel (zero between launches)
     size_t bytes;
 };
 
@@ -202,7 +203,16 @@ constexpr int kMaxHot = 64;                      // hot-row accumulator slots pe
 constexpr int kStripeSegmentRows = 16;         // segments of a plan that uses negative stripes (see rfm_fit_device, "segment length")
 static size_t max_segments(int64_t n_rows, int n_users) { return (size_t)n_users + (size_t)(n_rows / kStripeSegmentRows) + 1; }
 
-static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_feat_tab, int n_factors) {
+// floats of the features kernel's step ring: 2 slots per producer, one staged step (1 + 2F + P + Q floats) per row group of a
+// 1024-thread workgroup
+static size_t feat_ring_floats(const rfm_fit_config *c) {
+    if (!c->has_user_features && !c->has_item_features) return 0;
+    const ShapeEntry *sh = pick_shape(c->n_factors);
+    const size_t gpb = 1024 / (size_t)(sh ? sh->group : 16);
+    return 2 * (size_t)kFeatMaxProducers * gpb * (1 + 2 * (size_t)c->n_factors + (size_t)c->n_user_features + (size_t)c->n_item_features);
+}
+
+static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_ring, int n_factors) {
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
@@ -212,6 +222,7 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.hot_item = (int32_t *)(p + o);             o += align_up(sizeof(int32_t) * kMaxHot);
     w.hot_period = (int32_t *)(p + o);           o += align_up(sizeof(int32_t) * kMaxHot);
     w.sw_max_bits = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int));
+    w.feat_ring = (float *)(p + o);              o += align_up(sizeof(float) * n_ring);
     w.volatile_offset = o;
     w.ll = (double *)(p + o);                    o += align_up(sizeof(double) * epochs);
     w.draws = (unsigned long long *)(p + o);     o += align_up(sizeof(unsigned long long) * epochs);
@@ -220,7 +231,7 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.error_flags = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int) * 4);
     w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
     w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
-    w.feat_snapshot = (float *)(p + o);          o += align_up(sizeof(float) * n_feat_tab);
+    w.feat_flags = (unsigned int *)(p + o);      o += align_up(sizeof(unsigned int) * kFeatFlagWords);
     w.w_pad = (float *)(p + o);                  o += align_up(sizeof(float) * (size_t)kBiasStride * (size_t)n_items);
     w.hot_bins_v = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot * (size_t)n_factors);
     w.hot_bins_w = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot);
@@ -244,7 +255,7 @@ static int validate(const rfm_fit_config *c) {
         return RFM_ERR_UNKNOWN_SCHEDULE;
     if (c->mode != RFM_MODE_HOGWILD && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;
     if (c->tune_segment_rows < 0 || c->tune_segment_rows > kSegmentRows || c->tune_stripe_window < 0 || c->tune_stripe_rows < -1 ||
-        c->tune_hot_publications < 0 || c->tune_feature_waves < 0 || c->tune_table_every < 0 || c->tune_reserved[0] || c->tune_reserved[1])
+        c->tune_hot_publications < 0 || c->tune_feature_waves < 0 || c->tune_table_producers < 0 || c->tune_reserved[0] || c->tune_reserved[1])
         return RFM_ERR_BAD_ARG;
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
     if (c->rng == RFM_RNG_MT19937 && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;   // one serial stream
@@ -372,7 +383,7 @@ int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps)
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
-    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_table_floats(cfg), cfg->n_factors).bytes;
+    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors).bytes;
 }
 
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
@@ -385,7 +396,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     if ((rc = device_ok()) != RFM_OK) return rc;
     const int E = cfg->epochs;
     const int64_t N = cfg->n_interactions;
-    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_table_floats(cfg), cfg->n_factors);
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_ring_floats(cfg), cfg->n_factors);
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
@@ -532,7 +543,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     if (cfg->tune_feature_waves > 0) feat_waves = std::max(2, std::min(16, cfg->tune_feature_waves));
     // (the table trainer also stages one step per row group: 1 + 2F + P + Q floats each; wide tables take smaller workgroups)
     while (feat_waves > 2 && sizeof(float) * (feat_table_floats(cfg) + (size_t)feat_waves * (64 / shape->group) *
-                                              (1 + 2 * (size_t)cfg->n_factors + cfg->n_user_features + cfg->n_item_features)) > kLdsBytes)
+                                              (2 + 2 * (size_t)cfg->n_factors + cfg->n_user_features + cfg->n_item_features) + 1) > kLdsBytes)
         feat_waves /= 2;
     const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : ((use_hot || use_stripes) ? 16 : 4));   // see sgd_segments_kernel
     // stripe geometry: as many rows as the LDS left by the hot-row accumulators holds (at most 256: more rows mean longer
@@ -544,7 +555,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         stripe_rows = std::max(1, std::min(stripe_rows, cfg->n_items));
         stripe_rows_cap = stripe_rows;
     }
-    int grid = 1;
+    int grid = 1, n_producers = 0;
+    const bool feat_frozen = (cfg->debug_flags & 32) != 0;
     int64_t max_groups = 0;
     int64_t units_per_launch = units > 0 ? units : 1;
     if (!serial) {
@@ -577,9 +589,18 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         if (cfg->n_workgroups > 0) cap = cfg->n_workgroups;
         grid = (int)(need < cap ? need : cap);
         if (grid < 1 || single_group) grid = 1;
-        // features kernel: workgroup 0 is the table trainer -- one of the resident workgroups, not an extra one (a workgroup that
-        // had to wait for a free CU would run its share after everybody else)
-        if (use_segments && feat && !single_group) grid = (int)std::min<int64_t>((int64_t)grid + 1, std::max<int64_t>(cap, 2));
+        // features kernel: workgroup 0 is the table trainer and workgroups 1 .. n_producers stage the steps it applies
+        // (sgd_features_kernel) -- resident workgroups like the others, not extra ones (a workgroup that had to wait for a free
+        // CU would run its share after everybody else).  A producer delivers ~4 staged steps per microsecond, a row loop
+        // workgroup trains ~5 rows in that time: one producer per ~16 row-loop workgroups lets the trainer see every ~20th row
+        // of the stream until its own apply rate (~30 steps per microsecond) is the limit.
+        if (use_segments && feat && !single_group && !feat_frozen) {
+            const int64_t room = std::max<int64_t>(cap, 3);
+            n_producers = (int)std::max<int64_t>(1, std::min<int64_t>(12, ((int64_t)grid + 15) / 16));
+            if (cfg->tune_table_producers > 0) n_producers = std::min(kFeatMaxProducers, cfg->tune_table_producers);
+            if (grid + 1 + n_producers > room) grid = (int)std::max<int64_t>(1, room - 1 - n_producers);
+            grid += 1 + n_producers;
+        }
     }
     const int launches = (int)((units + units_per_launch - 1) / units_per_launch);
     if (use_stripes) {
@@ -623,7 +644,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
 
     // ---- plan, part 3: Hogwild damping.  n(row) = interactions in flight x the row's share of the data (+ what the other
     //      workgroups hold unpublished for a hot row); scale = min(1, M / n)
-    long long in_flight = single_group ? 1 : (long long)grid * waves_per_block * groups_per_wave;
+    long long in_flight = single_group ? 1 : (long long)(grid - (n_producers > 0 ? 1 + n_producers : 0)) * waves_per_block * groups_per_wave;
     if (!single_group && max_groups > 0 && max_groups < in_flight) in_flight = max_groups;
     const float damp_cap = damp ? damp_m * (float)N / (float)in_flight : 0.0f;
     // a user's in-flight SEGMENT publishes its accumulated steps only when it ends: count a concurrent segment as its length
@@ -714,6 +735,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.launch_index = 0;
         a.stripe_cover = stripe_rows > 0 ? std::min(1.0f, (float)grid * (float)stripe_rows / (float)cfg->n_items) : 0.0f;
         a.block_threads = waves_per_block * 64;
+        a.feat_ring = ws.feat_ring; a.feat_flags = ws.feat_flags; a.n_producers = n_producers; a.feat_frozen = feat_frozen ? 1 : 0;
         // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
         a.eta = cfg->learning_schedule == RFM_SCHEDULE_CONSTANT
                     ? cfg->learning_rate
@@ -785,6 +807,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     int status = RFM_OK;
     int epochs_done = E, bad_array = -1;
     if (h_err[0] & 3u) status = RFM_ERR_USER_SATURATED;
+    if (h_err[0] & 8u) { g_last_error = "features kernel: a workgroup gave up waiting for the table trainer / a step producer"; status = RFM_ERR_HIP; }
     for (int e = 0; e < epochs_launched && status == RFM_OK; ++e) {
         if (cfg->check_finite && h_nonfinite[e]) {
             for (int k = 0; k < 6; ++k)

@@ -96,6 +96,12 @@ struct SgdArgs {
     int32_t stripe_rows, stripe_window;
     uint32_t item_bits, launch_index;
     float stripe_cover;                         // share of the catalogue that sits in some workgroup's stripe at any time, <= 1
+    // features kernel: the step producers hand their batches to the table trainer through `feat_ring` ([2 * n_producers] slots of
+    // one staged step per row group of a workgroup), synchronised by the counters in `feat_flags` (sgd_features_kernel)
+    float *feat_ring;
+    unsigned int *feat_flags;
+    int32_t n_producers;
+    int32_t feat_frozen;                        // debug: the feature tables are not trained (no trainer, no producers)
 };
 constexpr int kHotBins = 16;
 
@@ -420,7 +426,8 @@ struct RowStep {
     }
 
     __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_, TabPtr v_uf, TabPtr v_if, TabPtr w_if)
-        : a(args), sub(sub_), F(args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
+        : a(args), sub(sub_), F(STRIPE ? G * KPL : args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
+    // (stripe launches are planned for full factor rows only: the factor count is the compile-time constant G * KPL there)
 
     __device__ __forceinline__ int dword_f(int k) const { return sub + G * k; }
     // (stripe launches are planned for FULL factor rows only, F == G * KPL: no per-dword predicate -- a v_cmp, an exec-mask
@@ -1068,7 +1075,7 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
     if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
-    const int F = a.n_factors;
+    const int F = STRIPE ? G * KPL : a.n_factors;
     extern __shared__ __attribute__((aligned(16))) float lds_tables[];
     lds_float *lds = (lds_float *)lds_tables;
     typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, WARPB, STRIPE> Step;
@@ -1301,27 +1308,93 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
 // and each touch shrinks the touched rows by 2 beta eta: in the sequential algorithm they are an exponential moving average of
 // the last ~1 / (2 beta eta) = 50-170 updates' gradients, i.e. they forget within a tiny fraction of an epoch.  16 k
 // interactions in flight cannot share such rows Hogwild-style (thousands of stale shrinks diverge), and per-workgroup replicas
-// that evolve independently and are merged now and then drift apart: the item biases, which every workgroup shares, are then
-// pulled by 256 different w_if / v_if at once (measured on config 4's share: log-likelihood +6 %, |w_i| +14 % against the
-// sequential oracle, and the more replicas the worse: profiles/r02_notes.md).  So the tables are trained by ONE sequential stream
-// and read, coherently, by everybody:
-//   * the TABLE TRAINER is workgroup 0.  Each of its row groups samples an interaction of the rank's data at random, scores it
-//     exactly like a regular step and computes the step's updated v_u and v_i - v_j WITHOUT storing them (the rows themselves
-//     are trained when their own turn comes) and stages them in LDS; then the reference's table updates of the 64 interactions
-//     are applied in order, all table rows in parallel (the rows of the tables do not read each other), on the workgroup's LDS
-//     master copy, which is published to the weight arrays in memory after every step -- a few million rows per second, i.e.
-//     hundreds of table memories per epoch.  A sequential SGD stream on a uniform sample of the rows: the same process that drives the
-//     tables in the reference, with the same memory and the same noise level (that matters: on random tags the tables ARE
-//     mostly noise, and averaging replicas visibly shrinks them);
-//   * every other workgroup runs the usual asynchronous row loop (user segments, v_u in registers, atomics for v_i / w_i) with
-//     the tables as a READ-ONLY copy in its workgroup's LDS, refreshed from memory every few rows by the wavefronts in turn
-//     (system-scope loads: the per-XCD L2s are not coherent, and a 16 KB table that is re-read all the time would otherwise
-//     never leave them).  No lock-step, no barrier in the loop.
-// One group alone (debug_flags bit 0) does both in the reference's order -- the sequential form the parity tests pin.
+// that evolve independently and are merged now and then drift apart (measured: profiles/r02_notes.md).  So the tables are trained
+// by ONE sequential stream and read, coherently, by everybody.  Roles by workgroup index:
+//   * 0: the TABLE TRAINER.  It applies the reference's table updates (:283-286, :313-326) of a stream of interactions in order
+//     on a master copy in its LDS -- all table rows in parallel, one row group per table row with the row in registers (the rows
+//     of the tables do not read each other), walking only the interactions that touch the row -- and publishes the copy to the
+//     weight arrays after every batch.  The interactions' steps come to it ready-made:
+//   * 1 .. n_producers: STEP PRODUCERS.  Each row group samples an interaction of the rank's data at random, scores it exactly
+//     like a regular step and stages the step's g * d_outer, updated v_u, updated v_i - v_j, x_uf[u] and x_if[i] - x_if[j]
+//     WITHOUT storing any row (the rows are trained when their own turn comes); a batch of one staged step per row group goes to
+//     the trainer through a double-buffered slot in memory.  A step is a chain of ~5 dependent gathers (~15 us), applying 64 of
+//     them takes ~2 us: round 2's trainer produced its own steps and so managed every ~150th row of the stream, which showed in
+//     the first epoch from random weights (the item biases picked up what the tables carry in the reference); with the steps
+//     produced beside it the trainer's rate is its apply rate -- a sequential SGD stream on a uniform sample of every ~20th-40th
+//     row, the same process that drives the tables in the reference, with the same memory and the same noise level.
+//   * the rest: the asynchronous ROW LOOP (user segments, v_u in registers, atomics for v_i / w_i) with the tables as a READ-ONLY
+//     copy in the workgroup's LDS that its wavefronts keep refreshing, a slice per wavefront and row (system-scope loads: the
+//     per-XCD L2s are not coherent, and a 16 KB table that is re-read all the time would otherwise never leave them).  No
+//     lock-step, no barrier in the loop.  BPR models with at most 32 + 32 features on 16-lane row groups take the pipelined form
+//     (FeatFast below), everything else the generic RowStep.
+// One group alone (debug_flags bit 0) does everything in the reference's order -- the sequential form the parity tests pin; with
+// debug_flags bit 5 (tables frozen: no trainer, no producers) one group alone runs the pipelined row loop sequentially, which
+// pins THAT code to the oracle as well.
 // ---------------------------------------------------------------------------------------------
+#define RFM_REP8(X, O) X(O + 0) X(O + 1) X(O + 2) X(O + 3) X(O + 4) X(O + 5) X(O + 6) X(O + 7)
+typedef float rfm_f4 __attribute__((ext_vector_type(4)));
+typedef float rfm_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) rfm_f4 lds_f4;
+typedef __attribute__((address_space(3))) rfm_f2 lds_f2;
+
+// flags of one launch of the features kernel (SgdArgs::feat_flags, zero between launches)
+constexpr int kFeatMaxProducers = 16;
+constexpr int kFeatReady = 0;                                  // [2 * producers] batches written into each slot
+constexpr int kFeatConsumed = 2 * kFeatMaxProducers;           // [2 * producers] batches the trainer has taken out of each slot
+constexpr int kFeatStop = 4 * kFeatMaxProducers;               // the regular workgroups are done
+constexpr int kFeatExited = kFeatStop + 1;                     // producers that have left
+constexpr int kFeatDone = kFeatStop + 2;                       // regular workgroups that have finished
+constexpr int kFeatFlagWords = kFeatStop + 4;
+constexpr unsigned kFeatSpinLimit = 1u << 23;                  // polls (~0.5 us each) before a waiting workgroup gives up: seconds
+
+__device__ __forceinline__ unsigned flag_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void flag_store(unsigned int *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// The pipelined row loop keeps its LDS copy of v_uf / v_if LANE-MAJOR: the KPL factor dwords lane s of a row group owns (s, s + 16,
+// ...) are consecutive, so a table row costs the lane one 16-byte LDS read instead of KPL 4-byte ones.  Row stride 16 * KPL.
+template <int KPL>
+__device__ __forceinline__ void lds_row_load(const lds_float *p, float (&t)[KPL]) {
+    if constexpr (KPL % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < KPL / 4; ++q) {
+            const rfm_f4 v = *(const lds_f4 *)(p + 4 * q);
+            t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+        }
+    } else if constexpr (KPL % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < KPL / 2; ++q) {
+            const rfm_f2 v = *(const lds_f2 *)(p + 2 * q);
+            t[2 * q] = v.x; t[2 * q + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) t[k] = p[k];
+    }
+}
+
+// acc[k] += sum_t x[t] * table[t][this lane's dwords], t = 0 .. n-1 (n <= 32): x is held across the 16 lanes of the group (lane s:
+// x[s] in xr0, x[s + 16] in xr1; entries >= n are zero) and reaches all lanes through a DPP row_share -- one VALU move per tag, no
+// ballot / shuffle walk over the non-zero entries (zero entries add an exact zero; the reference skips them, :73, :81).  The table
+// is padded with zero rows to a multiple of 8.
+template <int KPL>
+__device__ __forceinline__ void project_dense(float xr0, float xr1, int n, const lds_float *tab_lane, float (&acc)[KPL]) {
+    constexpr int FS = 16 * KPL;
+#define RFM_PSTEP(B)                                                                      \
+    {                                                                                     \
+        const float x = dpp_mov<0x150 + ((B) & 15)>(((B) < 16) ? xr0 : xr1);              \
+        float t[KPL];                                                                     \
+        lds_row_load<KPL>(tab_lane + (B) * FS, t);                                        \
+        _Pragma("unroll") for (int k = 0; k < KPL; ++k) acc[k] = __builtin_fmaf(x, t[k], acc[k]); \
+    }
+    if (n > 0) { RFM_REP8(RFM_PSTEP, 0) }
+    if (n > 8) { RFM_REP8(RFM_PSTEP, 8) }
+    if (n > 16) { RFM_REP8(RFM_PSTEP, 16) }
+    if (n > 24) { RFM_REP8(RFM_PSTEP, 24) }
+#undef RFM_PSTEP
+}
+
 template <int G, int KPL, bool FRESH, bool WARPB>
 __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
-    constexpr int GPW = 64 / G;                                    // row groups per wavefront
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int sub = lane % G;
     const int F = a.n_factors;
@@ -1329,27 +1402,128 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
     lds_float *lds = (lds_float *)lds_tables;
     const int n_uf_f = a.n_uf * F, n_if_f = a.n_if * F, n_tab = n_uf_f + n_if_f + a.n_if;
     auto table_ptr = [&](int k) { return k < n_uf_f ? a.v_uf + k : (k < n_uf_f + n_if_f ? a.v_if + (k - n_uf_f) : a.w_if + (k - n_uf_f - n_if_f)); };
-    for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
-    __syncthreads();
-    unsigned int *done_counter = a.error_flags + 3;                // regular workgroups that have finished this launch
+    const int NP = a.single_group ? 0 : a.n_producers;               // (one group alone: no trainer, no producers)
+    const bool trains = !a.single_group && !a.feat_frozen;
+    unsigned int *flags = a.feat_flags;
+    const int gid = threadIdx.x / G, gpb = blockDim.x / G;
+    const int n_slot = 1 + 2 * F + a.n_uf + a.n_if;                  // staged step of one interaction (RowStep::stage)
+    const size_t batch_floats = (size_t)gpb * n_slot;
+    const int n_regular = (int)gridDim.x - (trains ? 1 + NP : 0);
 
-    if (!a.single_group && blockIdx.x == 0) {
-        // ---- the table trainer
+    if (trains && blockIdx.x <= (unsigned)NP) {
+        // natural layout of the tables: [P, F] | [Q, F] | [Q]
+        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
+        lds_float *stage = lds + n_tab;
+        __shared__ int s_stop;
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            // ---- the table trainer ------------------------------------------------------------------------------------------
+            const float eta_f = a.eta, reg_b = a.reg_b;
+            // rho^n, n = 0 .. gpb: w_if shrinks on EVERY interaction (:283-286), also those whose tag difference is zero, which the
+            // row walk below skips
+            lds_float *rho_pow = stage + batch_floats;
+            if (threadIdx.x <= (unsigned)gpb) rho_pow[threadIdx.x] = powf(1.0f - eta_f * reg_b, (float)threadIdx.x);
+            for (unsigned q = 0;; ++q) {
+                const int p = NP > 0 ? (int)(q % (unsigned)NP) : 0;
+                const unsigned n_p = NP > 0 ? q / (unsigned)NP : q, par = n_p & 1u, m = n_p >> 1;
+                if (threadIdx.x == 0) {
+                    int stop = 0;
+                    for (unsigned spin = 0;; ++spin) {
+                        if (NP > 0 && flag_load(flags + kFeatReady + 2 * p + par) >= m + 1u) break;
+                        if (flag_load(flags + kFeatDone) >= (unsigned)n_regular) { stop = 1; break; }
+                        if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }      // (never observed: a hang guard)
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    s_stop = stop;
+                }
+                __syncthreads();
+                if (s_stop) break;
+                const float *src = a.feat_ring + (size_t)(2 * p + par) * batch_floats;
+                for (size_t k = threadIdx.x; k < batch_floats; k += blockDim.x)
+                    stage[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __syncthreads();
+                if (threadIdx.x == 0) flag_store(flags + kFeatConsumed + 2 * p + par, m + 1u);
+                // Apply the staged steps.  Within one interaction the table rows do not read each other, so the reference's
+                // sequential update of the tables over the batch (rankfm/_rankfm.pyx:283-286, 313-326) is, for each table ROW, a walk
+                // over the interactions that touch it -- all rows at once, one row group per row with the row in registers, plain
+                // read and write.  The interactions that touch the row are found by the group's lanes together (one ballot per G
+                // staged steps); the row of v_if for tag q also carries w_if[q] (lane 0).
+                for (int r = gid; r < a.n_uf + a.n_if; r += gpb) {
+                    const bool uf = r < a.n_uf;
+                    if (uf ? !a.has_uf : !a.has_if) continue;
+                    lds_float *row = lds + (size_t)r * F;                                  // v_uf rows, then v_if rows
+                    const int xoff = 1 + 2 * F + r, voff = uf ? 1 + F : 1;                   // coefficient; vector: v_i - v_j | v_u
+                    float tr[KPL];
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k) tr[k] = (sub + G * k < F) ? row[sub + G * k] : 0.0f;
+                    float wq = uf ? 0.0f : lds[n_uf_f + n_if_f + (r - a.n_uf)];
+                    int last = -1;                                                          // last staged step applied to w_if[q]
+                    for (int c0 = 0; c0 < gpb; c0 += G) {
+                        const int mine = c0 + sub;
+                        const bool on = mine < gpb && stage[(size_t)mine * n_slot + xoff] != 0.0f;
+                        unsigned long long bits;
+                        if constexpr (G == 64) bits = __ballot(on);
+                        else bits = (unsigned long long)group_ballot<G>(on);
+                        while (bits) {
+                            const int b = __ffsll((long long)bits) - 1;
+                            bits &= bits - 1;
+                            const int s2 = c0 + b;
+                            const lds_float *st = stage + (size_t)s2 * n_slot;
+                            const float c = st[0] * st[xoff];
+#pragma unroll
+                            for (int k = 0; k < KPL; ++k)
+                                if (sub + G * k < F) tr[k] += eta_f * (c * st[voff + sub + G * k] - reg_b * tr[k]);
+                            if (!uf) {
+                                wq = wq * rho_pow[s2 - last - 1];                          // the untouched interactions in between
+                                wq += eta_f * (c - reg_b * wq);
+                                last = s2;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (sub + G * k < F) row[sub + G * k] = tr[k];
+                    if (!uf && sub == 0) lds[n_uf_f + n_if_f + (r - a.n_uf)] = wq * rho_pow[gpb - 1 - last];
+                }
+                __syncthreads();
+                // publish the master copy (write-through to memory)
+                for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
+                    __hip_atomic_store(table_ptr(k), lds_tables[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            // the launch is over: release the producers, wait until they have left, and leave the flags zero for the next launch
+            if (threadIdx.x == 0) {
+                flag_store(flags + kFeatStop, 1u);
+                for (unsigned spin = 0; flag_load(flags + kFeatExited) < (unsigned)NP && spin <= kFeatSpinLimit; ++spin) __builtin_amdgcn_s_sleep(8);
+                for (int k = 0; k < kFeatFlagWords; ++k) flag_store(flags + k, 0u);
+            }
+            return;
+        }
+        // ---- a step producer ----------------------------------------------------------------------------------------------------
         typedef RowStep<G, KPL, false, true, true, true, true, false, WARPB, false, 1> Train;
         Train step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
-        const int gid = threadIdx.x / G, gpb = blockDim.x / G;
-        const int n_slot = 1 + 2 * F + a.n_uf + a.n_if;            // staged step of one interaction (RowStep::stage)
-        lds_float *stage = lds + n_tab;
-        __shared__ int stop;
+        const int p = (int)blockIdx.x - 1;
         double ll_unused = 0.0;
         unsigned draws_unused = 0;
-        for (uint32_t n = 0;; ++n) {
-            if (threadIdx.x == 0)
-                stop = __hip_atomic_load(done_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= gridDim.x - 1 ? 1 : 0;
+        for (unsigned n = 0;; ++n) {
+            const unsigned par = n & 1u, m = n >> 1;
+            if (threadIdx.x == 0) {
+                int stop = 0;
+                for (unsigned spin = 0;; ++spin) {           // the slot must have been emptied m times
+                    if (flag_load(flags + kFeatStop)) { stop = 1; break; }
+                    if (flag_load(flags + kFeatConsumed + 2 * p + par) >= m) break;
+                    if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                s_stop = stop;
+            }
             __syncthreads();
-            if (stop) break;
+            if (s_stop) break;
+            // this batch is scored on the tables as published now
+            for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
+                lds_tables[k] = __hip_atomic_load(table_ptr(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
             // a uniformly random row: a random segment (accepted with probability length / 32) and a random row of it
-            uint32_t h = rfm_mix32(a.epoch_key ^ rfm_mix32((n * gpb + gid) * 0x9E3779B9U + 0x3C6EF372U + a.launch_index));
+            uint32_t h = rfm_mix32(a.epoch_key ^ rfm_mix32(((n * (unsigned)NP + (unsigned)p) * (unsigned)gpb + (unsigned)gid) * 0x9E3779B9U + 0x3C6EF372U + a.launch_index));
             int4 d;
             for (;;) {
                 d = a.seg_desc[rfm_draw_to_item(h, (uint32_t)a.n_segments)];
@@ -1368,59 +1542,23 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
             step.stage = stage + (size_t)gid * n_slot;
             step(rfm_mix32(h ^ 0xC2B2AE35U), u, i, sw, lo, hi, vu, ll_unused, draws_unused);
             __syncthreads();
-            // Apply the staged steps.  Within one interaction the table rows do not read each other, so the reference's
-            // sequential update of the tables over the gpb staged interactions (rankfm/_rankfm.pyx:283-286, 313-326) is, for each
-            // table ROW, a walk over the interactions that touch it -- all rows at once, one 16-lane group per row with the row
-            // in registers, plain read and write.
-            const float eta_f = a.eta, reg_b = a.reg_b;
-            for (int r = gid; r < a.n_uf + a.n_if; r += gpb) {
-                const bool uf = r < a.n_uf;
-                if (uf ? !a.has_uf : !a.has_if) continue;
-                lds_float *row = lds + (size_t)r * F;                                  // v_uf rows, then v_if rows
-                const int xoff = 1 + 2 * F + r, voff = uf ? 1 + F : 1;                   // coefficient; vector: v_i - v_j | v_u
-                float tr[KPL];
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) tr[k] = (sub + G * k < F) ? row[sub + G * k] : 0.0f;
-                for (int s2 = 0; s2 < gpb; ++s2) {
-                    const lds_float *st = stage + (size_t)s2 * n_slot;
-                    const float x = st[xoff];
-                    if (x == 0.0f) continue;                                            // rows the interaction does not touch keep their value
-                    const float c = st[0] * x;
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        if (sub + G * k < F) tr[k] += eta_f * (c * st[voff + sub + G * k] - reg_b * tr[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < KPL; ++k)
-                    if (sub + G * k < F) row[sub + G * k] = tr[k];
-            }
-            if (a.has_if)
-                for (int q = threadIdx.x; q < a.n_if; q += blockDim.x) {               // w_if: every interaction shrinks every q
-                    float w = lds[n_uf_f + n_if_f + q];
-                    for (int s2 = 0; s2 < gpb; ++s2) {
-                        const lds_float *st = stage + (size_t)s2 * n_slot;
-                        w += eta_f * (st[0] * st[1 + 2 * F + a.n_uf + q] - reg_b * w);
-                    }
-                    lds[n_uf_f + n_if_f + q] = w;
-                }
-            __syncthreads();
-            // publish the master copy (write-through to memory)
-            for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
-                __hip_atomic_store(table_ptr(k), lds_tables[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            float *dst = a.feat_ring + (size_t)(2 * p + par) * batch_floats;
+            for (size_t k = threadIdx.x; k < batch_floats; k += blockDim.x)
+                __hip_atomic_store(dst + k, stage[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // this wavefront's stores have been performed ...
+            __syncthreads();                                     // ... and everybody's, before the slot is announced
+            if (threadIdx.x == 0) flag_store(flags + kFeatReady + 2 * p + par, m + 1u);
         }
-        if (threadIdx.x == 0) __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // for the next launch
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + kFeatExited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
 
-    // ---- regular workgroups (1 .. grid-1): the asynchronous row loop of sgd_segments_kernel, tables read-only
-    const int64_t gpb = blockDim.x / G;
-    const int64_t group = a.single_group ? (int64_t)threadIdx.x / G : ((int64_t)blockIdx.x - 1) * gpb + threadIdx.x / G;
-    int64_t n_groups = a.single_group ? gpb : ((int64_t)gridDim.x - 1) * gpb;
+    // ---- regular workgroups: the asynchronous row loop, tables read-only -------------------------------------------------------
+    const int first_regular = trains ? 1 + NP : 0;
+    const int64_t group = a.single_group ? (int64_t)threadIdx.x / G : ((int64_t)blockIdx.x - first_regular) * gpb + threadIdx.x / G;
+    int64_t n_groups = a.single_group ? gpb : (int64_t)n_regular * gpb;
     if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
-    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 0> Reg;
-    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 2> Both;
-    Reg step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
-    Both both(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     double ll_acc = 0.0;
     unsigned draw_acc = 0;
     int64_t sp = a.pos_begin + (a.single_group ? 0 : group);
@@ -1433,12 +1571,202 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
     float vu[KPL], vu0[KPL];
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
-    constexpr int kRefreshEvery = 4;                               // rows between table refreshes of a workgroup
+
+    constexpr bool FAST_SHAPE = G == 16 && !WARPB;
+    const bool fast = FAST_SHAPE && a.n_uf <= 32 && a.n_if <= 32 && (!a.single_group || a.feat_frozen);
+    if constexpr (FAST_SHAPE) {
+      if (fast) {
+        // ---- the pipelined row loop (BPR, <= 32 + 32 features, 16-lane row groups) -------------------------------------------
+        constexpr int FS = G * KPL;                                     // LDS row stride (rows are padded to full width)
+        const int P8 = (a.n_uf + 7) & ~7, Q8 = (a.n_if + 7) & ~7;     // tables padded with zero rows to a multiple of 8
+        lds_float *t_uf = lds, *t_if = lds + (size_t)P8 * FS, *t_wif = lds + (size_t)(P8 + Q8) * FS;
+        const int n_fast = (P8 + Q8) * FS + a.n_if;
+        // LDS element e of the lane-major copy <- table element (global), or zero padding
+        auto refresh = [&](int e) {
+            float v = 0.0f;
+            if (e < (P8 + Q8) * FS) {
+                const int r = e / FS, w = e % FS, f = (w % KPL) * G + w / KPL;     // lane w / KPL, its dword w % KPL
+                if (f < F) {
+                    if (r < P8) { if (r < a.n_uf) v = __hip_atomic_load(a.v_uf + (size_t)r * F + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                    else if (r - P8 < a.n_if) v = __hip_atomic_load(a.v_if + (size_t)(r - P8) * F + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            } else v = __hip_atomic_load(a.w_if + (e - (P8 + Q8) * FS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            lds_tables[e] = v;
+        };
+        for (int e = threadIdx.x; e < n_fast; e += blockDim.x) refresh(e);
+        __syncthreads();
+        typedef RowStep<G, KPL, false, true, true, FRESH, true, false, false, false, 0> Reg;
+        Reg step(a, sub, lds, lds, lds);                               // (draws, membership test, user damping; its tables are unused)
+        const lds_float *uf_lane = t_uf + sub * KPL, *if_lane = t_if + sub * KPL;
+        const int lane_base = lane - sub;
+        const float multiplier = a.multiplier[1];                       // :269 with sampled == 1
+        const float eta = a.eta, reg_a = a.reg_a;
+        constexpr int SEGR = (kSegmentRows + G - 1) / G;
+        int32_t seg_item[SEGR], seg_pos[SEGR];
+        float seg_sw[SEGR];
+        float xu0 = 0.0f, xu1 = 0.0f;
+        // the positive item's row, bias + step scale (one padded line), tags: fetched one row ahead
+        struct Pos { float v[KPL]; float w, scale, x0, x1; } cur, nxt;
+        auto fetch_pos = [&](int32_t it, Pos &p) {
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) p.v[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_i + (size_t)it * F + sub + G * k) : 0.0f;
+            if (a.scale_in_pad) {
+                const float x = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride + (sub & 1));
+                p.w = __shfl(x, lane_base);
+                p.scale = __shfl(x, lane_base + 1);
+            } else {
+                p.w = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
+                p.scale = a.pos_scale ? a.pos_scale[it] : 1.0f;
+            }
+            p.x0 = p.x1 = 0.0f;
+            if (a.has_if) {
+                const float *x = a.x_if + (size_t)it * a.n_if;
+                if (sub < a.n_if) p.x0 = x[sub];
+                if (sub + G < a.n_if) p.x1 = x[sub + G];
+            }
+        };
+        auto pick = [&](const int32_t (&r)[SEGR], int tt) {
+            int32_t x = r[0];
+#pragma unroll
+            for (int k = 1; k < SEGR; ++k) x = ((unsigned)tt / G == (unsigned)k) ? r[k] : x;
+            return x;
+        };
+        auto pickf = [&](const float (&r)[SEGR], int tt) {
+            float x = r[0];
+#pragma unroll
+            for (int k = 1; k < SEGR; ++k) x = ((unsigned)tt / G == (unsigned)k) ? r[k] : x;
+            return x;
+        };
+        for (int iter = 0; __any(active); ++iter) {
+            // every wavefront refreshes its slice of the workgroup's copy on every row (readers may see a row half old, half new: both
+            // are tables the trainer published)
+            if (trains) {
+                const int per = (n_fast + n_waves - 1) / n_waves, e0 = wave * per, e1 = e0 + per < n_fast ? e0 + per : n_fast;
+                for (int e = e0 + lane; e < e1; e += 64) refresh(e);
+            }
+            if (active && !have) {
+                const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
+                const int4 d = a.seg_desc[seg];
+                u = d.x; begin = d.y; len = d.z;
+                lo = a.csr_off[u]; hi = a.csr_off[u + 1];
+                len_bits = (int32_t)rfm_perm_bits((uint32_t)len);
+                seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) {
+                    vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                    vu[k] = vu0[k];
+                }
+                t = 0;
+                have = true;
+                step.load_ulist(lo, hi);
+                xu0 = xu1 = 0.0f;
+                if (a.has_uf) {
+                    const float *x = a.x_uf + (size_t)u * a.n_uf;
+                    if (sub < a.n_uf) xu0 = x[sub];
+                    if (sub + G < a.n_uf) xu1 = x[sub + G];
+                }
+                // the segment's rows in visiting order, held across the lanes (row t in lane t % G, register t / G)
+#pragma unroll
+                for (int k = 0; k < SEGR; ++k) {
+                    const int tt = sub + G * k;
+                    seg_pos[k] = tt < len ? begin + (int32_t)rfm_perm((uint32_t)tt, (uint32_t)len, (uint32_t)len_bits, seg_key) : begin;
+                    seg_item[k] = a.csr_items[seg_pos[k]];
+                    seg_sw[k] = a.sw_csr[seg_pos[k]];
+                }
+                fetch_pos(__shfl(pick(seg_item, 0), lane_base), nxt);
+            }
+            if (active) {
+                const int src = lane_base + (int)((unsigned)t % G);
+                const int32_t pos = __shfl(pick(seg_pos, t), src), i = __shfl(pick(seg_item, t), src);
+                const float sw = __shfl(pickf(seg_sw, t), src);
+                cur = nxt;
+                // (one group alone is a sequential program: a repeated (user, item) row must see the previous row's update)
+                if (a.single_group) fetch_pos(i, cur);
+                else if (t + 1 < len) fetch_pos(__shfl(pick(seg_item, t + 1), lane_base + (int)((unsigned)(t + 1) % G)), nxt);   // overlaps this row
+                const uint32_t row_key = rfm_row_key(a.epoch_key, (uint32_t)pos);
+                // the negative (:250-253) and its gathers
+                uint32_t attempt = 0;
+                int srow_unused;
+                const int32_t j = step.next_negative(lo, hi, row_key, attempt, srow_unused);
+                float vj[KPL], wj, xj0 = 0.0f, xj1 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) vj[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_i + (size_t)j * F + sub + G * k) : 0.0f;
+                wj = load_f32<FRESH>(a.w_i + (size_t)j * a.w_stride);
+                if (a.has_if) {
+                    const float *x = a.x_if + (size_t)j * a.n_if;
+                    if (sub < a.n_if) xj0 = x[sub];
+                    if (sub + G < a.n_if) xj1 = x[sub + G];
+                }
+                // A = x_uf[u] . v_uf (:297-300), while the negative's row is on its way
+                float A[KPL], Bd[KPL];
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) A[k] = Bd[k] = 0.0f;
+                if (a.has_uf) project_dense<KPL>(xu0, xu1, a.n_uf, uf_lane, A);
+                // pairwise utility (:239, :256-257 regrouped: both the utility and the gradients need the item-feature terms only as
+                // differences):  pu = (w_i - w_j) + (x_i - x_j).w_if + <v_u + A, v_i - v_j> + <(x_i - x_j).v_if, v_u>
+                float part = 0.0f;
+                const float dx0 = cur.x0 - xj0, dx1 = cur.x1 - xj1;
+                if (a.has_if) {
+                    project_dense<KPL>(dx0, dx1, a.n_if, if_lane, Bd);
+                    if (sub < a.n_if) part = dx0 * t_wif[sub];
+                    if (sub + G < a.n_if) part += dx1 * t_wif[sub + G];
+                }
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) part += (vu[k] + A[k]) * (cur.v[k] - vj[k]) + Bd[k] * vu[k];
+                const float pu = (cur.w - wj) + group_sum<G>(part);
+                float log_sig, d_outer;
+                sigmoid_terms(pu, log_sig, d_outer);                              // :270, :276
+                if (sub == 0) { ll_acc += (double)log_sig; draw_acc += 1u; }
+                const float g = sw * multiplier;
+                const float eta_u = eta * step.user_scale, eta_i = eta * cur.scale;
+                float *pi = a.v_i + (size_t)i * F + sub, *pj = a.v_i + (size_t)j * F + sub;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) {
+                    const float g_u = (cur.v[k] - vj[k]) + Bd[k];                                     // :292, :303-305
+                    const float g_i = vu[k] + A[k];                                                   // :293-294, :297-300
+                    const float d_u = eta_u * (g * (d_outer * g_u) - reg_a * vu[k]);                  // :308
+                    const float d_i = eta_i * (g * (d_outer * g_i) - reg_a * cur.v[k]);               // :309
+                    const float d_j = eta * (g * (d_outer * -g_i) - reg_a * vj[k]);                   // :310
+                    vu[k] += d_u;
+                    if (sub + G * k < F) { atomic_add_f32(pi + G * k, d_i); atomic_add_f32(pj + G * k, d_j); }
+                }
+                if (sub == 0) {
+                    atomic_add_f32(a.w_i + (size_t)i * a.w_stride, eta_i * (g * (d_outer * 1.0f) - reg_a * cur.w));    // :279
+                    atomic_add_f32(a.w_i + (size_t)j * a.w_stride, eta * (g * (d_outer * -1.0f) - reg_a * wj));        // :280
+                }
+                if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next row reads what this one wrote
+                if (++t == len) {
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                    if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                    have = false;
+                    sp += stride;
+                    active = sp < a.pos_end;
+                }
+            }
+        }
+        if (trains) {
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + kFeatDone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        flush_counters(a, ll_acc, draw_acc);
+        return;
+      }
+    }
+
+    // ---- generic row loop (WARP, wide feature vectors, other row-group shapes; one group alone: both rows and tables) -----------
+    for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
+    __syncthreads();
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 0> Reg;
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 2> Both;
+    Reg step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
+    Both both(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
+    const bool train_here = a.single_group && !a.feat_frozen;          // one group alone trains the tables in its LDS
     for (int iter = 0; __any(active); ++iter) {
-        if (!a.single_group && iter % kRefreshEvery == 0 && (iter / kRefreshEvery) % n_waves == wave) {
-            // this wavefront's turn to bring the workgroup's copy up to date (readers may see a row half old, half new:
-            // both are tables the trainer published)
-            for (int k = lane; k < n_tab; k += 64)
+        if (trains) {
+            const int per = (n_tab + n_waves - 1) / n_waves, e0 = wave * per, e1 = e0 + per < n_tab ? e0 + per : n_tab;
+            for (int k = e0 + lane; k < e1; k += 64)
                 lds_tables[k] = __hip_atomic_load(table_ptr(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (active && !have) {
@@ -1460,7 +1788,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
             const int32_t pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);
             const int32_t i = a.csr_items[pos];
             const float sw = a.sw_csr[pos];
-            if (a.single_group) both(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+            if (train_here) both(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
             else step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
             if (++t == len) {
 #pragma unroll
@@ -1472,11 +1800,11 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
             }
         }
     }
-    if (!a.single_group) {
+    if (trains) {
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + kFeatDone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (a.single_group) {             // the one group trained the tables in its LDS: store them
+    if (train_here) {             // the one group trained the tables in its LDS: store them
         for (int k = threadIdx.x; k < n_tab; k += blockDim.x) *table_ptr(k) = lds_tables[k];
     }
     flush_counters(a, ll_acc, draw_acc);

@@ -169,3 +169,43 @@ def make_planted(n_users=6040, n_items=3706, rank=16, seed=0, mean_degree=165.0,
         out["user_tags"] = (A[:, :n_tags] > 0).astype(np.float32)
         out["item_tags"] = (B[:, :n_tags] > 0).astype(np.float32)
     return out
+
+
+def _planted_chunk(args):
+    """top-deg items of a block of users under the planted score model (worker of make_planted_large)"""
+    seed, c, u0, u1, n_items, rank, deg, B, pop = args
+    rng = np.random.default_rng([seed, 1000 + c])
+    A = rng.normal(size=(u1 - u0, rank)).astype(np.float32)
+    S = 0.75 * (A @ B.T) + pop
+    S += rng.gumbel(size=S.shape).astype(np.float32)
+    d_max = int(deg.max())
+    top = np.argpartition(-S, d_max - 1, axis=1)[:, :d_max]                     # the d_max best of every row, unordered
+    top = np.take_along_axis(top, np.argsort(-np.take_along_axis(S, top, axis=1), axis=1), axis=1)     # ... best first
+    keep = np.arange(d_max)[None, :] < deg[:, None]
+    users = np.repeat(np.arange(u0, u1, dtype=np.int32), deg)
+    return users, top[keep].astype(np.int32)
+
+
+def make_planted_large(n_users, n_items, rank=16, seed=0, mean_degree=60.0, max_degree=1000, holdout=0.25, processes=None, chunk=2048):
+    """make_planted's score model (3/4 <A_u, B_i> + popularity + Gumbel noise, clipped log-normal degrees) for problems of
+    BASELINE config 2's size: user blocks are generated independently (seeded per block, in a process pool) and the top items of
+    a row are found by partial selection instead of a full sort.  NOT the same random stream as make_planted -- the reference-minted
+    quality fixtures stay on make_planted.  Returns dict(train [n,2] int32, test [m,2] int32)."""
+    import multiprocessing as mp
+    rng = np.random.default_rng([seed, 0])
+    B = rng.normal(size=(n_items, rank)).astype(np.float32)
+    pop = np.empty(n_items, dtype=np.float32)
+    pop[rng.permutation(n_items)] = -0.5 * np.log(np.arange(1, n_items + 1))
+    deg = np.clip(rng.lognormal(np.log(mean_degree) - 0.5, 1.0, n_users), 10, min(max_degree, n_items // 2)).astype(np.int64)
+    tasks = [(seed, c, u0, min(u0 + chunk, n_users), n_items, rank, deg[u0:u0 + chunk], B, pop)
+             for c, u0 in enumerate(range(0, n_users, chunk))]
+    processes = min(len(tasks), processes or min(32, os.cpu_count() or 1))
+    if processes > 1:
+        with mp.get_context("fork").Pool(processes) as pool:
+            parts = pool.map(_planted_chunk, tasks)
+    else:
+        parts = [_planted_chunk(t) for t in tasks]
+    pairs = np.stack([np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])], 1)
+    pairs = pairs[rng.permutation(len(pairs))]
+    n_test = int(len(pairs) * holdout)
+    return dict(test=np.ascontiguousarray(pairs[:n_test]), train=np.ascontiguousarray(pairs[n_test:]), user_tags=None, item_tags=None)

@@ -120,3 +120,26 @@ def test_product_never_imports_the_oracle():
             text = open(path).read()
             assert "librfm_oracle" not in text and "rfm_oracle" not in text.replace("oracle/rfm_oracle.c", ""), path
             assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), path
+
+
+def test_the_library_reads_no_environment_variable():
+    """the C ABI (rfm_fit_config) and nothing else steers the engine: no getenv in the sources of the library, so a stray
+    environment variable cannot change the algorithm under the drop-in boundary, and the host mirror (rankfm_amd/order.py),
+    which sees only the report, cannot disagree with the kernel"""
+    import glob
+    srcs = [p for ext in ("*.hip", "*.hpp", "*.inc") for p in glob.glob(os.path.join(ROOT, "rankfm_amd", "csrc", ext))]
+    assert len(srcs) >= 4
+    for p in srcs:
+        assert "getenv" not in open(p).read(), p
+
+
+def test_geometry_overrides_are_validated(lib):
+    cfg = _hip.FitConfig(n_interactions=10, n_users=4, n_items=5, n_user_features=1, n_item_features=1, n_factors=8, max_samples=1,
+                         epochs=1, learning_schedule=0, mode=0, rng=1)
+    assert lib.rfm_fit_supported(C.byref(cfg)) == _hip.OK
+    for bad in (dict(tune_segment_rows=33), dict(tune_stripe_rows=-2), dict(tune_stripe_window=-1), dict(tune_table_producers=-1)):
+        c2 = _hip.FitConfig(n_interactions=10, n_users=4, n_items=5, n_user_features=1, n_item_features=1, n_factors=8, max_samples=1,
+                            epochs=1, learning_schedule=0, mode=0, rng=1, **bad)
+        assert lib.rfm_fit_supported(C.byref(c2)) == _hip.ERR_BAD_ARG, bad
+    with pytest.raises(ValueError):
+        _hip.tune_kwargs({"stripe_widow": 3})

@@ -233,6 +233,13 @@ def test_end_to_end_drop_in_reproduces_the_reference(case):
             assert np.array_equal(got, want), key
         else:
             assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]), key
+    # similar_items / similar_users: the reference's own output (rankfm/rankfm.py:405-454) for a few query rows
+    for q, want in zip(g["sim_item_queries"], g["sim_items"]):
+        got = m.similar_items(q if str_ids else int(q), n_items=6)
+        assert np.array_equal(np.asarray(got).astype(want.dtype), want), ("similar_items", q, got, want)
+    for q, want in zip(g["sim_user_queries"], g["sim_users"]):
+        got = m.similar_users(q if str_ids else int(q), n_users=6)
+        assert np.array_equal(np.asarray(got).astype(want.dtype), want), ("similar_users", q, got, want)
     assert evaluation.hit_rate(m, test, k=7) == pytest.approx(float(g["hit_rate"]), abs=1e-12)
     assert evaluation.hit_rate(m, test, k=7, filter_previous=True) == pytest.approx(float(g["hit_rate_new"]), abs=1e-12)
     assert evaluation.reciprocal_rank(m, test, k=7) == pytest.approx(float(g["reciprocal_rank"]), abs=1e-9)

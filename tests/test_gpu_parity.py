@@ -81,7 +81,8 @@ def _problem(U, I, N, F, seed, n_uf=0, n_if=0, sigma=0.1, random_sw=False):
     return pairs, csr, sw, x_uf, x_if, w
 
 
-def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1, schedule="constant", geometry=None):
+def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1, schedule="constant", geometry=None, plain_sampler=False,
+                            **oracle_kw):
     """The sequential CPU oracle on exactly the order and draws of the Hogwild segments kernel: interactions re-ordered to
     CSR positions (the kernel keys its counter RNG by CSR position), visiting order and -- given the launch `geometry` the
     engine reported -- the negative stripe of every row from rankfm_amd.order."""
@@ -96,12 +97,14 @@ def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1,
     o = {k: v.copy() for k, v in w0.items()}
     out = oracle.fit(pairs_csr, sw_csr, csr.offsets, csr.items, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"],
                      o["v_if"], 0.01, 0.1, lr, schedule, 0.25, max_samples, epochs, perms=perms, rng_mode=oracle.RNG_COUNTER,
-                     seed=seed, membership="binary", want_negatives=len(pairs) <= 1_000_000,
-                     **order.oracle_stripes(csr.offsets, seed, range(epochs), geometry, len(w0["w_i"])))
+                     seed=seed, membership="binary", want_negatives=len(pairs) <= 1_000_000, **oracle_kw,
+                     # plain_sampler: the REFERENCE'S sampler (every draw uniform over the catalogue, rankfm/_rankfm.pyx:250-253) on the
+                     # engine's order, instead of the engine's own negative stripes
+                     **({} if plain_sampler else order.oracle_stripes(csr.offsets, seed, range(epochs), geometry, len(w0["w_i"]))))
     return o, out
 
 
-def _both(oracle, prob, max_samples, epochs, seed=5, lr=0.1, engine_kw=None):
+def _both(oracle, prob, max_samples, epochs, seed=5, lr=0.1, engine_kw=None, **oracle_kw):
     from rankfm_amd import EngineOptions
     from rankfm_amd._rankfm import _fit
     pairs, csr, sw, x_uf, x_if, w0 = prob
@@ -110,7 +113,7 @@ def _both(oracle, prob, max_samples, epochs, seed=5, lr=0.1, engine_kw=None):
     _fit(pairs, sw, csr, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"],
          0.01, 0.1, lr, "constant", 0.25, max_samples, epochs, False,
          engine=EngineOptions(mode="hogwild", seed=seed, **(engine_kw or {})), report=rep)
-    o, out = _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr, geometry=rep["geometry"])
+    o, out = _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr, geometry=rep["geometry"], **oracle_kw)
     return g, rep, o, out
 
 
@@ -132,6 +135,30 @@ def test_hogwild_kernel_on_one_group_is_the_sequential_algorithm(oracle, F, max_
         np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg=k)
     np.testing.assert_allclose(rep["log_likelihood"], out["ll"], rtol=1e-4)
     assert np.array_equal(rep["n_draws"], out["nsamp"].sum(axis=1))
+
+
+@pytest.mark.parametrize("F, n_uf, n_if", [(64, 32, 32), (16, 4, 5), (20, 8, 8), (32, 0, 6), (128, 20, 32), (48, 7, 0), (8, 1, 1)])
+def test_feature_row_loop_on_one_group_is_the_sequential_algorithm_on_frozen_tables(oracle, F, n_uf, n_if):
+    """The pipelined row loop of sgd_features_kernel (BPR, <= 32 + 32 features: lane-major LDS tables, dense DPP projections, the
+    positive item's row and tags fetched a row ahead) restricted to ONE row group with the table trainer switched off
+    (debug_flags bits 0 + 5) is a sequential program: it must reproduce the oracle with frozen feature tables
+    (`table_every=-1`: rankfm/_rankfm.pyx:233-310 without :283-286, :313-326) to the serial tolerance.  (With the trainer on, one
+    group alone takes the generic step that also trains the tables -- test_hogwild_kernel_on_one_group_...)"""
+    prob = _problem(U=120, I=90, N=3000, F=F, seed=F + n_uf, n_uf=n_uf, n_if=n_if, random_sw=True)
+    lr = 0.02 if n_uf + n_if > 20 else 0.1
+    g, rep, o, out = _both(oracle, prob, 1, epochs=2, seed=9, lr=lr, engine_kw=dict(debug_flags=1 | 32), table_every=-1)
+    for k in WEIGHTS:
+        np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg=k)
+    for k in ("v_uf", "v_if", "w_if"):
+        assert np.array_equal(g[k], prob[5][k]), k                       # frozen means frozen
+    np.testing.assert_allclose(rep["log_likelihood"], out["ll64"], rtol=1e-4)
+
+
+def test_feature_row_loop_hogwild_tracks_the_oracle_on_frozen_tables(oracle):
+    """... and at full concurrency (tables still frozen, so that only the row loop is compared): norms 2 %, log-likelihood 2 %"""
+    prob = _problem(U=3000, I=2000, N=120_000, F=64, seed=22, n_uf=32, n_if=32)
+    g, rep, o, out = _both(oracle, prob, 1, epochs=2, lr=0.03, engine_kw=dict(debug_flags=32), table_every=-1)
+    _assert_statistical_parity(g, rep, o, out, corr=0.97)
 
 
 def _assert_statistical_parity(g, rep, o, out, names=("v_u", "v_i", "w_i"), norm_tol=0.02, ll_tol=0.02, corr=0.98):

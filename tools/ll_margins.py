@@ -147,6 +147,13 @@ def main():
                                     norms={k: float(np.linalg.norm(g[k])) for k in WEIGHTS})
             submit(tag="C3:%d:oracle" % r, data="C2", weights=wp, max_samples=50, epochs=[3], seed=1492, lr=0.1, geometry_order=s.geometry(),
                    stripes=False)
+            if a.damped and r == 0:
+                cfg2 = synthetic.CONFIGS["C2"]
+                pos, user = step_scales(s, DATA["C2"], cfg2["n_items"], cfg2["n_users"])
+                sp = os.path.join(TMP, "c3_steps.npz")
+                np.savez(sp, pos=pos, user=user)
+                submit(tag="C3:0:damped_oracle", data="C2", weights=wp, max_samples=50, epochs=[3], seed=1492, lr=0.1, geometry_order=s.geometry(),
+                       stripes=False, steps=sp)
             del s
     # ---- config 4, one GPU's share: first epoch from the initial weights, second epoch from the GPU's weights -----------------
     if "C4" in configs:
@@ -195,6 +202,8 @@ def main():
                 compare("C2:nostripes:%d" % r, "C2:nostripes:damped_oracle")
         if "C3" in configs:
             compare("C3:%d" % r, "C3:%d:oracle" % r)
+            if a.damped and r == 0:
+                compare("C3:0", "C3:0:damped_oracle")
         if "C4" in configs:
             compare("C4:e1:%d" % r, "C4:e1:oracle", WEIGHTS)
             compare("C4:e2:%d" % r, "C4:e2:%d:oracle" % r, WEIGHTS)

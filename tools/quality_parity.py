@@ -30,6 +30,9 @@ ap.add_argument("--dampings", default="0")
 ap.add_argument("--variants", default="", help="engine variants for the GPU sides, ';'-separated; a variant is a ','-separated list of "
                 "'nostripes' and geometry overrides (rfm_fit_config tune_*): e.g. ';nostripes;segment_rows=32;stripe_window=12,segment_rows=32'")
 ap.add_argument("--seed0", type=int, default=0)
+ap.add_argument("--large", action="store_true", help="synthetic.make_planted_large (config-2-sized problems) instead of make_planted")
+ap.add_argument("--degree", type=float, default=60.0, help="mean degree of make_planted_large")
+ap.add_argument("--metrics", default="hit,mrr,prec,rec")
 a = ap.parse_args()
 
 rows = []
@@ -39,7 +42,8 @@ def engine_of(variant, **kw):
 
 
 for seed in range(a.seed0, a.seed0 + a.seeds):
-    d = synthetic.make_planted(a.users, a.items, seed=seed, n_tags=a.tags)
+    d = (synthetic.make_planted_large(a.users, a.items, seed=seed, mean_degree=a.degree) if a.large
+         else synthetic.make_planted(a.users, a.items, seed=seed, n_tags=a.tags))
     train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
     uf = itf = None
     if a.tags:
@@ -64,14 +68,14 @@ for seed in range(a.seed0, a.seed0 + a.seeds):
                     ms, a.epochs, perms=None, rng_mode=orc.RNG_COUNTER, seed=100 + seed, membership="binary")
             m.is_fit = True
         dt = time.time() - t0
-        res[side] = dict(hit=evaluation.hit_rate(m, test, k=10), mrr=evaluation.reciprocal_rank(m, test, k=10),
-                         prec=evaluation.precision(m, test, k=10), rec=evaluation.recall(m, test, k=10),
+        fns = dict(hit=evaluation.hit_rate, mrr=evaluation.reciprocal_rank, prec=evaluation.precision, rec=evaluation.recall)
+        res[side] = dict({k: fns[k](m, test, k=10) for k in a.metrics.split(",")},
                          nvu=np.linalg.norm(m.v_u), nvi=np.linalg.norm(m.v_i), nwi=np.linalg.norm(m.w_i), t=dt)
     rows.append(res)
     print("seed %d  n_train %d" % (seed, len(train)), {s: {k: round(float(v), 4) for k, v in r.items()} for s, r in res.items()}, flush=True)
 for side in [s for s in rows[0] if s != "oracle"]:
     print("==", side)
-    for k in ("hit", "mrr", "prec", "rec", "nvu", "nvi", "nwi", "t"):
+    for k in a.metrics.split(",") + ["nvu", "nvi", "nwi", "t"]:
         o = np.array([r["oracle"][k] for r in rows]); g = np.array([r[side][k] for r in rows])
         print("%-5s oracle %.4f +- %.4f   gpu %.4f +- %.4f   diff %+.4f (%+.2f%%)" % (k, o.mean(), o.std(), g.mean(), g.std(), g.mean() - o.mean(),
               100 * (g.mean() - o.mean()) / o.mean()))
