@@ -76,6 +76,45 @@ def cpu_baseline(shard, x_if, w, hyper, has_uf, has_if, seconds_budget=25.0):
                        % (n_rows, t, os.cpu_count() or 0))
 
 
+def strong_scaling_record(world, rank, device, steps, warmup, barrier):
+    """N > 1 only: BASELINE config 4 as ONE data set sharded by user over the ranks (strong scaling: 50 M interactions whatever N),
+    timed like the main line -- barrier + synchronize on both sides, max over ranks.  A sub-record of the JSON line; the main line
+    stays the weak-scaling config-2 workload the metric is quoted on."""
+    import torch
+    import torch.distributed as dist
+    from rankfm_amd import synthetic
+    from rankfm_amd.distributed import SHARED_NAMES, broadcast_from_rank0, make_device_trainer
+    cfg = synthetic.CONFIGS["C4"]
+    sh = synthetic.make_config_shard("C4", rank=rank, world=world)
+    w = sh["weights"]
+    shard = dict(interactions=sh["interactions"], sample_weight=sh["sample_weight"], csr_offsets=sh["csr_offsets"], csr_items=sh["csr_items"],
+                 x_uf=sh["x_uf"], v_u=w["v_u"])
+    hyper = dict(alpha=0.01, beta=0.1, learning_rate=cfg["learning_rate"], learning_schedule="constant", learning_exponent=0.25, max_samples=1)
+    trainer, _ = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, sh["x_if"], hyper, device, seed=1492,
+                                     has_user_features=1, has_item_features=1)
+    broadcast_from_rank0([trainer.shared.flat])
+    epoch = 0
+    for _ in range(warmup):
+        trainer.run_epoch(epoch)
+        epoch += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rep = trainer.run_epoch(epoch)
+        epoch += 1
+    barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    assert np.isfinite(float(rep["log_likelihood"][0]))
+    return {"workload": "C4: ONE synthetic data set of %d users x %d items x %d interactions + %d + %d dense features, factors=%d, bpr, "
+                        "sharded by user over %d GPUs, one RCCL all-reduce of the item-side deltas (%.1f MB) per epoch"
+                        % (cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["n_user_features"], cfg["n_item_features"], cfg["factors"],
+                           world, trainer.shared.payload_bytes / 1e6),
+            "scaling": "strong", "value": float(cfg["n_interactions"]) * steps / elapsed, "unit": "updates/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "n_gpus": world}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +134,7 @@ def main():
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
     ap.add_argument("--weak", action="store_true", help="configs 4 / 5: weak scaling (every rank its own config-sized shard)")
     ap.add_argument("--learning-rate", type=float, default=0.0, help="override the config's learning rate")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sub-record (config 4 sharded over the ranks)")
     ap.add_argument("--tune", default="", help="geometry overrides of rfm_fit_config (experiments): 'stripe_window=12,segment_rows=32'")
     args = ap.parse_args()
 
@@ -192,6 +232,9 @@ def main():
         elapsed = float(t.item())
     ll_last = float(rep["log_likelihood"][0])
     assert np.isfinite(ll_last), "training diverged"
+    strong_rec = None
+    if world > 1 and args.config == "C2" and not args.no_strong and not share_gpu:
+        strong_rec = strong_scaling_record(world, rank, device, max(2, min(args.steps, 5)), 1, barrier)
 
     if rank == 0:
         N = n_local
@@ -264,6 +307,8 @@ def main():
                          "kernel": "rfm::sgd_features_kernel" if (n_uf or n_if) else "rfm::sgd_segments_kernel", "kernel_ms_per_launch": k_ms,
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }
+        if strong_rec is not None:
+            out["strong_scaling"] = strong_rec
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shard, x_if, w, hyper, int(n_uf > 0), int(n_if > 0))
         print(json.dumps(out))

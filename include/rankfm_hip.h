@@ -177,6 +177,14 @@ int rfm_device_count(void);                  /* number of gfx950 devices visible
 int rfm_fit_supported(const rfm_fit_config *cfg);          /* RFM_OK or the error rfm_fit_* would return */
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg); /* 0 on a bad config */
 
+/* Multi-GPU exchange step (rankfm_amd/distributed.py; no reference counterpart -- the reference is single-process): the item-side
+ * tables of a rank live in ONE flat fp32 bucket, and the per-epoch exchange is  delta = flat - start;  all-reduce(delta);
+ * flat = start + scale .* delta.  These two entry points are the single pass over the bucket on each side of the collective
+ * (the all-reduce itself is RCCL's, driven by the caller).  dev_scale: per-element damping of the summed deltas, or NULL for the
+ * uniform factor `uniform_scale` (1 = plain sum, 1 / ranks = average). */
+int rfm_delta_begin(float *dev_flat, const float *dev_start, size_t n, void *hip_stream);
+int rfm_delta_finish(float *dev_flat, const float *dev_start, const float *dev_scale, float uniform_scale, size_t n, void *hip_stream);
+
 /* Measurement aid (bench.py `roofline.peak_measured`): the rate at which this box's HBM serves a plain streaming kernel over
  * `bytes` of device memory -- a read-only pass and a copy (read + write), best of `iters` launches each, in GB/s.  The SGD
  * path's roofline is quoted against the 8 TB/s data-sheet peak AND against this achievable figure. */

@@ -201,7 +201,12 @@ static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 constexpr int kMaxHot = 64;                      // hot-row accumulator slots per workgroup (LDS: kMaxHot * (F + 2) floats)
 
 constexpr int kStripeSegmentRows = 16;         // segments of a plan that uses negative stripes (see rfm_fit_device, "segment length")
-static size_t max_segments(int64_t n_rows, int n_users) { return (size_t)n_users + (size_t)(n_rows / kStripeSegmentRows) + 1; }
+// (a user of degree d is cut into ceil(d / rows) <= d / rows + 1 segments)
+static size_t max_segments(int64_t n_rows, int n_users, int seg_rows) { return (size_t)n_users + (size_t)(n_rows / seg_rows) + 1; }
+// shortest segment length a plan of this call may use: 16 (stripe plans), or the caller's override when that is shorter
+static int min_segment_rows(const rfm_fit_config *c) {
+    return c->tune_segment_rows > 0 && c->tune_segment_rows < kStripeSegmentRows ? c->tune_segment_rows : kStripeSegmentRows;
+}
 
 // floats of the features kernel's step ring: 2 slots per producer, one staged step (1 + 2F + P + Q floats) per row group of a
 // 1024-thread workgroup
@@ -212,13 +217,14 @@ static size_t feat_ring_floats(const rfm_fit_config *c) {
     return 2 * (size_t)kFeatMaxProducers * gpb * (1 + 2 * (size_t)c->n_factors + (size_t)c->n_user_features + (size_t)c->n_item_features);
 }
 
-static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_ring, int n_factors) {
+static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_ring, int n_factors,
+                       int seg_rows_min) {
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
     w.pos_scale = (float *)(p + o);              o += align_up(sizeof(float) * (size_t)n_items);
     w.sw_csr = (float *)(p + o);                 o += align_up(sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1));
-    w.seg_desc = (int4 *)(p + o);                o += align_up(sizeof(int4) * max_segments(n_rows, n_users));
+    w.seg_desc = (int4 *)(p + o);                o += align_up(sizeof(int4) * max_segments(n_rows, n_users, seg_rows_min));
     w.hot_item = (int32_t *)(p + o);             o += align_up(sizeof(int32_t) * kMaxHot);
     w.hot_period = (int32_t *)(p + o);           o += align_up(sizeof(int32_t) * kMaxHot);
     w.sw_max_bits = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int));
@@ -300,6 +306,36 @@ __global__ void __launch_bounds__(256) stream_probe_kernel(const float4 *__restr
     if (!COPY && acc == 123456.789f) *sink = acc;        // keeps the loads alive
 }
 
+// ---------------------------------------------------------------------------------------------
+// multi-GPU exchange (rankfm_amd/distributed.py): one pass over the flat bucket of item-side tables on each side of the all-reduce
+//   begin:  flat <- flat - start                      (this rank's deltas of the epoch)
+//   finish: flat <- start + scale .* flat             (start + damped sum of all ranks' deltas; scale per element or uniform)
+// ---------------------------------------------------------------------------------------------
+template <bool FINISH>
+__global__ void __launch_bounds__(256) delta_kernel(float *__restrict__ flat, const float *__restrict__ start, const float *__restrict__ scale,
+                                                    float uniform, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, n4 = n >> 2;
+    const bool vec = ((reinterpret_cast<uintptr_t>(flat) | reinterpret_cast<uintptr_t>(start) | reinterpret_cast<uintptr_t>(scale)) & 15) == 0;
+    size_t done = 0;
+    if (vec) {
+        float4 *f4 = reinterpret_cast<float4 *>(flat);
+        const float4 *s4 = reinterpret_cast<const float4 *>(start), *c4 = reinterpret_cast<const float4 *>(scale);
+        for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += stride) {
+            float4 f = f4[k];
+            const float4 s = s4[k];
+            if (FINISH) {
+                float4 c = make_float4(uniform, uniform, uniform, uniform);
+                if (scale) c = c4[k];
+                f.x = s.x + c.x * f.x; f.y = s.y + c.y * f.y; f.z = s.z + c.z * f.z; f.w = s.w + c.w * f.w;
+            } else { f.x -= s.x; f.y -= s.y; f.z -= s.z; f.w -= s.w; }
+            f4[k] = f;
+        }
+        done = n4 << 2;
+    }
+    for (size_t k = done + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        flat[k] = FINISH ? start[k] + (scale ? scale[k] : uniform) * flat[k] : flat[k] - start[k];
+}
+
 }  // namespace rfm
 
 using namespace rfm;
@@ -343,6 +379,24 @@ int rfm_device_count(void) {
 
 int rfm_fit_supported(const rfm_fit_config *cfg) { return validate(cfg); }
 
+int rfm_delta_begin(float *dev_flat, const float *dev_start, size_t n, void *hip_stream) {
+    if (!dev_flat || !dev_start) return RFM_ERR_BAD_ARG;
+    if (n == 0) return RFM_OK;
+    const int grid = (int)std::min<size_t>(2048, (n / 4 + 255) / 256 + 1);
+    delta_kernel<false><<<dim3(grid), dim3(256), 0, (hipStream_t)hip_stream>>>(dev_flat, dev_start, nullptr, 1.0f, n);
+    RFM_HIP(hipGetLastError());
+    return RFM_OK;
+}
+
+int rfm_delta_finish(float *dev_flat, const float *dev_start, const float *dev_scale, float uniform_scale, size_t n, void *hip_stream) {
+    if (!dev_flat || !dev_start) return RFM_ERR_BAD_ARG;
+    if (n == 0) return RFM_OK;
+    const int grid = (int)std::min<size_t>(2048, (n / 4 + 255) / 256 + 1);
+    delta_kernel<true><<<dim3(grid), dim3(256), 0, (hipStream_t)hip_stream>>>(dev_flat, dev_start, dev_scale, uniform_scale, n);
+    RFM_HIP(hipGetLastError());
+    return RFM_OK;
+}
+
 int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps) {
     int rc = device_ok();
     if (rc != RFM_OK) return rc;
@@ -383,7 +437,7 @@ int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps)
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
-    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors).bytes;
+    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg)).bytes;
 }
 
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
@@ -396,7 +450,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     if ((rc = device_ok()) != RFM_OK) return rc;
     const int E = cfg->epochs;
     const int64_t N = cfg->n_interactions;
-    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_ring_floats(cfg), cfg->n_factors);
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg));
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
@@ -464,7 +518,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     }
     if (use_segments && build_plan) {
         std::vector<int4> desc;
-        desc.reserve(max_segments(N, cfg->n_users));
+        desc.reserve(max_segments(N, cfg->n_users, seg_rows));
         for (int u = 0; u < cfg->n_users; ++u) {
             const int64_t d = off[u + 1] - off[u];
             if (d <= 0) continue;
@@ -475,6 +529,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             }
         }
         n_segments = (int64_t)desc.size();
+        if (desc.size() > max_segments(N, cfg->n_users, min_segment_rows(cfg))) return RFM_ERR_WORKSPACE;       // (cannot happen: see max_segments)
         RFM_HIP(hipMemcpyAsync(ws.seg_desc, desc.data(), sizeof(int4) * desc.size(), hipMemcpyHostToDevice, stream));
         RFM_HIP(hipMemsetAsync(ws.sw_csr, 0xFF, sizeof(float) * (size_t)N, stream));
         RFM_HIP(hipMemsetAsync(ws.sw_max_bits, 0, sizeof(unsigned int), stream));

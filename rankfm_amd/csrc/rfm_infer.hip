@@ -299,6 +299,7 @@ __global__ void __launch_bounds__(256) topn_select_kernel(const float *__restric
     // the n_rec-th best segment maximum (selected maxima are struck out of the LDS copy as they are found)
     float tv = -INFINITY;
     int ti = -1;
+    bool take_all = false;      // fewer than n_rec segments hold a rankable element: every rankable element is a candidate
     for (int r = 0; r < n_rec; ++r) {
         float bv = -INFINITY;
         int bi = -1, bs = -1;
@@ -307,7 +308,10 @@ __global__ void __launch_bounds__(256) topn_select_kernel(const float *__restric
         float gv = bv;
         int gi = bi;
         block_best(gv, gi, w_val, w_idx);
-        if (gi < 0) break;                                                // fewer than n_rec rankable elements
+        // fewer than n_rec segments with a rankable element (a user who has seen nearly everything, NaN scores): the last maximum
+        // found is NOT a lower bound of the top n_rec -- the non-maximal elements of those segments are needed to fill the list.
+        // They number at most (n_rec - 1) x segment length, which the candidate list holds.
+        if (gi < 0) { take_all = true; break; }
         tv = gv; ti = gi;
         if (bi == gi && bs >= 0) s_idx[bs] = -1;                           // (indexes are unique: exactly one thread strikes)
         __syncthreads();
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(256) topn_select_kernel(const float *__restric
         for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
             const float v = row[i];
             if (i == skip_index || !(v > -INFINITY)) continue;
-            if (i == ti || ranks_before(v, i, tv, ti)) {
+            if (take_all || i == ti || ranks_before(v, i, tv, ti)) {
                 const int c = atomicAdd(&n_cand, 1);
                 if (c < kCands) { s_val[c] = v; s_idx[c] = i; }
             }

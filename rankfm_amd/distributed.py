@@ -109,10 +109,26 @@ class SharedTables:
         """the exchange step: after it every rank holds epoch_start + sum (or mean) over ranks of its epoch's deltas"""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return
+        world = dist.get_world_size(group)
+        if self.flat.is_cuda:
+            # one fused pass over the bucket on each side of the collective (rfm_delta_begin / rfm_delta_finish) instead of four
+            # elementwise passes: the bucket is 52 MB at BASELINE config 4 and 516 MB at config 5
+            import ctypes as C
+            from . import _hip
+            with torch.cuda.device(self.flat.device):
+                stream = C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)
+                n = self.flat.numel()
+                _hip.raise_for_status(_hip.lib().rfm_delta_begin(self.flat.data_ptr(), self.start.data_ptr(), n, stream))
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                scale = None if (average or self.merge_scale is None) else self.merge_scale.data_ptr()
+                _hip.raise_for_status(_hip.lib().rfm_delta_finish(self.flat.data_ptr(), self.start.data_ptr(), scale,
+                                                                  1.0 / world if average else 1.0, n, stream))
+            return
+        # CPU tensors (the gloo tests of the N > 1 logic): the same arithmetic with torch ops
         self.flat.sub_(self.start)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         if average:
-            self.flat.div_(dist.get_world_size(group))
+            self.flat.div_(world)
         elif self.merge_scale is not None:
             self.flat.mul_(self.merge_scale)
         self.flat.add_(self.start)
@@ -178,19 +194,27 @@ class ShardedTrainer:
         return total
 
 
+def agree_on_merge_damping(shared, shard, group=None, merge_damping=None, syncs_per_epoch=1, learning_rate=0.1):
+    """the damped merge needs every item's update count over ALL ranks per exchange window: one all-reduce of the ranks' item
+    histograms, then SharedTables.set_merge_damping (a no-op without a process group / on one rank)"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    device = shared.flat.device
+    counts = torch.bincount(torch.as_tensor(np.asarray(shard["interactions"])[:, 1].astype(np.int64)),
+                            minlength=shared.views["w_i"].shape[0]).to(device=device, dtype=torch.float32)
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    # the damping counts updates per exchange window
+    shared.set_merge_damping(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), merge_damping,
+                             learning_rate=learning_rate)
+
+
 def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=None,
                         syncs_per_epoch=1, **session_kw):
     """wire a rank's shard to the HIP engine: weights are views into the flat bucket, so the engine's in-place
     atomics and the all-reduce act on the same memory"""
     from .engine import DeviceSession
     shared = SharedTables(shared_tables, device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        counts = torch.bincount(torch.as_tensor(np.asarray(shard["interactions"])[:, 1].astype(np.int64)),
-                                minlength=shared.views["w_i"].shape[0]).to(device=device, dtype=torch.float32)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-        # the damping counts updates per exchange window
-        shared.set_merge_damping(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), merge_damping,
-                                 learning_rate=hyper.get("learning_rate", 0.1))
+    agree_on_merge_damping(shared, shard, group, merge_damping, syncs_per_epoch, hyper.get("learning_rate", 0.1))
     if len(shard["csr_offsets"]) <= 1 or len(shard["interactions"]) == 0:
         # a rank without users (more ranks than users, or a few heavy users): it trains nothing but still joins every collective
         def idle_epoch(_views, epoch, part=None):
@@ -216,9 +240,9 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
     the SAME arguments and the same numpy seed.
 
-    Every rank maps the identifiers of the full data set (cheap, vectorised, identical on all ranks because numpy's RNG state
-    is), builds the sorted item lists of ITS users only, trains its user shard on its GPU and exchanges the item-side deltas
-    once per epoch (ShardedTrainer).  At the end the user factors and the item lists are all-gathered, so every rank returns the
+    Every rank maps the identifiers of ITS slice of the rows (the maps themselves are agreed on first, the mapped pairs are
+    all-gathered), builds the sorted item lists of ITS users only, trains its user shard on its GPU and exchanges the item-side
+    deltas once per epoch (ShardedTrainer).  At the end the user factors and the item lists are all-gathered, so every rank returns the
     complete fitted model with the reference's attribute layout.  With world size 1 this is `model.fit(...)` on the resident-session path.
 
     `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
@@ -229,13 +253,39 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if world > 1 else 0
     model._reset_state()
-    # Rank-local indexing: the identifier maps and the index pairs are global (cheap, vectorised, identical on every rank), but
-    # the per-user sorted item lists -- the one O(N log N) step of the front end -- are built by every rank for ITS users only and
-    # exchanged at the end.  The weights are drawn in full on every rank (numpy's stream must advance identically).
+    # Rank-local front end.  Identifier hashing is the expensive host step (one hash lookup per row and column): every rank maps only
+    # ITS slice of the rows -- rows [r N / W, (r + 1) N / W) -- after the ranks have agreed on the identifier <-> index maps (union
+    # of the slices' unique identifiers: U + I values exchanged, not N), and the mapped int32 pairs are all-gathered so that every
+    # rank ends with the reference's complete `interactions` attribute in the original row order.  The per-user sorted item lists
+    # -- the one O(N log N) step -- are built by every rank for ITS users only and exchanged at the end.  The weights are drawn in
+    # full on every rank (numpy's stream must advance identically).
     assert isinstance(interactions, (np.ndarray, pd.DataFrame)), "[interactions] must be np.ndarray or pd.dataframe"
     assert interactions.shape[1] == 2, "[interactions] should be: [user_id, item_id]"
-    model._init_ids(interactions)
-    pairs = model._index_pairs(interactions, sample_weight)
+    if world > 1:
+        from .utils import get_data
+        data = get_data(interactions)
+        n_rows = len(data)
+        r_lo, r_hi = n_rows * rank // world, n_rows * (rank + 1) // world
+        uniq = [None] * world
+        dist.all_gather_object(uniq, (pd.unique(data[r_lo:r_hi, 0]), pd.unique(data[r_lo:r_hi, 1])), group=group)
+        model._set_ids(np.sort(pd.unique(np.concatenate([u for u, _ in uniq]))), np.sort(pd.unique(np.concatenate([i for _, i in uniq]))))
+        mine = model._index_pairs(data[r_lo:r_hi], None)
+        comm_dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        longest = max(n_rows * (r + 1) // world - n_rows * r // world for r in range(world))
+        buf = torch.zeros((max(longest, 1), 2), dtype=torch.int32, device=comm_dev)
+        buf[:len(mine)] = torch.as_tensor(mine).to(comm_dev)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
+        pairs = np.concatenate([parts[r][:n_rows * (r + 1) // world - n_rows * r // world].cpu().numpy() for r in range(world)])
+        if sample_weight is not None:
+            assert isinstance(sample_weight, (np.ndarray, pd.Series)) and sample_weight.ndim == 1 and len(sample_weight) == n_rows, \
+                "[sample_weight] must be a vector as long as [interactions]"
+            model.sample_weight = np.ascontiguousarray(get_data(sample_weight), dtype=np.float32)
+        else:
+            model.sample_weight = np.ones(n_rows, dtype=np.float32)
+    else:
+        model._init_ids(interactions)
+        pairs = model._index_pairs(interactions, sample_weight)
     model.interactions = np.ascontiguousarray(pairs, dtype=np.int32)
     n_users = len(model.user_idx)
     offsets = np.zeros(n_users + 1, dtype=np.int64)
@@ -261,7 +311,11 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
         seed = int(np.random.randint(0, 2**31 - 1)) + rank if model.engine.seed is None else int(model.engine.seed) + rank
         trainer, sess = make_device_trainer(shard, tables, model.x_if, hyper, device, group=group, merge_damping=merge_damping,
                                             syncs_per_epoch=syncs_per_epoch, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
-                                            want_penalty=verbose, hogwild_damping=model.engine.damping)
+                                            want_penalty=verbose, hogwild_damping=model.engine.damping,
+                                            # every engine option of the single-GPU path applies to the shards as well
+                                            debug_flags=int(model.engine.debug_flags) | (0 if model.engine.negative_stripes else 8),
+                                            tune=model.engine.tune, n_workgroups=model.engine.n_workgroups,
+                                            rows_per_launch=model.engine.rows_per_launch, check_finite=model.engine.check_finite)
         finish = (lambda: sess.weights["v_u"].detach().cpu().numpy()) if sess is not None else (lambda: np.zeros((0, model.factors), np.float32))   # noqa: E731
     else:
         trainer, finish = make_trainer(shard, tables, model.x_if, hyper, device, group)

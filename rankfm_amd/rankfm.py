@@ -87,8 +87,12 @@ class RankFM():
         """the identifier <-> index maps: sorted unique identifiers, zero-based index = rank of the identifier
         (rankfm/rankfm.py:113-127)"""
         data = get_data(interactions)
-        self.user_id = pd.Series(np.sort(pd.unique(data[:, 0])))
-        self.item_id = pd.Series(np.sort(pd.unique(data[:, 1])))
+        self._set_ids(np.sort(pd.unique(data[:, 0])), np.sort(pd.unique(data[:, 1])))
+
+    def _set_ids(self, users_sorted, items_sorted):
+        """install the identifier <-> index maps from the sorted unique identifiers (fit_distributed builds those rank-locally)"""
+        self.user_id = pd.Series(users_sorted)
+        self.item_id = pd.Series(items_sorted)
         self.index_to_user = self.user_id
         self.index_to_item = self.item_id
         self.user_to_index = pd.Series(data=self.index_to_user.index, index=self.index_to_user.values)

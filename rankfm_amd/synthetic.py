@@ -176,7 +176,12 @@ def _planted_chunk(args):
     seed, c, u0, u1, n_items, rank, deg, B, pop = args
     rng = np.random.default_rng([seed, 1000 + c])
     A = rng.normal(size=(u1 - u0, rank)).astype(np.float32)
-    S = 0.75 * (A @ B.T) + pop
+    try:        # one BLAS thread per worker: a pool of workers x a 256-thread BLAS each thrashes a many-core host
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            S = 0.75 * (A @ B.T) + pop
+    except ImportError:
+        S = 0.75 * (A @ B.T) + pop
     S += rng.gumbel(size=S.shape).astype(np.float32)
     d_max = int(deg.max())
     top = np.argpartition(-S, d_max - 1, axis=1)[:, :d_max]                     # the d_max best of every row, unordered

@@ -149,7 +149,9 @@ def _fit_worker(rank, world, port, out_dir):
     ids = pd.DataFrame({"user_id": ["u%04d" % u for u in pairs[:, 0]], "item_id": pairs[:, 1] * 3 + 7})     # raw ids, not indexes
 
     def make_trainer(shard, tables, x_if, hyper, device, group):
+        from rankfm_amd.distributed import agree_on_merge_damping
         shared = SharedTables(tables, torch.device("cpu"))
+        agree_on_merge_damping(shared, shard, group, learning_rate=hyper["learning_rate"])      # like make_device_trainer
         x_uf = np.zeros((len(shard["v_u"]), 1), np.float32)
 
         def epoch_fn(views, epoch):
@@ -168,10 +170,15 @@ def _fit_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_fit_distributed_returns_the_full_model_on_every_rank(tmp_path):
-    """the user-facing multi-GPU fit on 2 gloo ranks (oracle as the epoch): identical complete models on both ranks"""
-    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    a, b = np.load(tmp_path / "fit0.npz"), np.load(tmp_path / "fit1.npz")
+@pytest.mark.parametrize("world", [2, 8])
+def test_fit_distributed_returns_the_full_model_on_every_rank(tmp_path, world):
+    """the user-facing multi-GPU fit on 2 and on EIGHT gloo ranks (oracle as the epoch, rank-local identifier mapping, damped
+    merge agreed over the ranks): identical complete models on every rank"""
+    mp.spawn(_fit_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "fit0.npz"), np.load(tmp_path / ("fit%d.npz" % (world - 1)))
+    for r in range(1, world - 1):
+        c = np.load(tmp_path / ("fit%d.npz" % r))
+        assert all(np.array_equal(a[k], c[k]) for k in ("v_u", "v_i", "w_i", "csr_items", "interactions"))
     for k in ("v_u", "v_i", "w_i"):
         assert np.array_equal(a[k], b[k]) and np.isfinite(a[k]).all(), k
     assert a["v_u"].shape == (U, F) and a["v_i"].shape == (I, F)

@@ -89,3 +89,34 @@ def test_fit_distributed_over_rccl():
         r = [np.load(os.path.join(d, "n%d.npz" % k)) for k in range(world)]
     for k in ("v_u", "v_i", "w_i"):
         assert np.isfinite(r[0][k]).all() and all(np.array_equal(r[0][k], x[k]) for x in r[1:]), k
+
+
+def test_fused_delta_kernels_match_the_elementwise_form():
+    """rfm_delta_begin / rfm_delta_finish (one pass over the bucket on each side of the all-reduce) against the four elementwise
+    torch passes they replace; odd length and a per-element scale, a uniform scale, and the plain sum"""
+    import ctypes as C
+    import torch
+    from rankfm_amd import _hip
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n = 1_000_003
+    flat = torch.randn(n, generator=g).to(dev)
+    start = torch.randn(n, generator=g).to(dev)
+    scale = torch.rand(n, generator=g).to(dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    want_delta = flat - start
+    f = flat.clone()
+    assert _hip.lib().rfm_delta_begin(f.data_ptr(), start.data_ptr(), n, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(f, want_delta)
+    for sc, uni in ((scale, 1.0), (None, 0.125), (None, 1.0)):
+        h = want_delta.clone()
+        assert _hip.lib().rfm_delta_finish(h.data_ptr(), start.data_ptr(), None if sc is None else sc.data_ptr(), uni, n, stream) == 0
+        torch.cuda.synchronize()
+        want = start + (sc if sc is not None else uni) * want_delta
+        assert torch.allclose(h, want, rtol=0, atol=1e-6)
+    # unaligned views (tables inside a bucket start at 256-byte boundaries, but the entry points must not assume it)
+    f2 = flat.clone()
+    assert _hip.lib().rfm_delta_begin(f2[1:].data_ptr(), start[1:].data_ptr(), n - 1, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(f2[1:], want_delta[1:]) and f2[0] == flat[0]

@@ -177,3 +177,25 @@ def test_duplicate_heavy_user_with_more_rows_than_items_trains(oracle):
     full = np.concatenate([np.stack([np.zeros(70, np.int64), np.concatenate([np.arange(50), rng.integers(0, 50, 20)])], 1), rest]).astype(np.int32)
     with pytest.raises(ValueError, match="every item"):
         _run(full, _csr(full, 25), np.ones(len(full), np.float32), 16, 1, 1, 5, {}, oracle)
+
+
+def test_recommend_for_a_user_who_has_seen_nearly_everything(oracle):
+    """top-n with `filter_previous` when fewer than n_rec of the 4096 score-row segments of the threshold selection
+    (rfm_infer.hip, topn_select_kernel) hold an unseen item: the selection must fall back to ranking every unseen item instead
+    of cutting at the last segment maximum it found (which dropped valid items and returned NaN slots)."""
+    from rankfm_amd import synthetic
+    from rankfm_amd._rankfm import UserItemsCSR, _recommend
+    U, I, F, n_rec = 3, 5000, 8, 10                           # 5000 items -> 2500 segments of two elements (i, i + 2500)
+    w = synthetic.init_weights(U, I, F, sigma=0.5, seed=4)
+    w["w_i"] = np.random.default_rng(1).normal(0, 0.3, I).astype(np.float32)
+    unseen = np.array([0, 2500, 1, 2501, 2, 2502, 3, 2503, 4, 2504, 5, 2505])      # 12 items in SIX segments
+    lists = [np.setdiff1d(np.arange(I), unseen).astype(np.int32), np.arange(0, I, 7, dtype=np.int32), np.zeros(0, np.int32)]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+    csr = UserItemsCSR(off, np.concatenate(lists))
+    args = (np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32), w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"])
+    users = np.array([0, 1, 2], np.float32)
+    rec = _recommend(users, csr, n_rec, True, *args)
+    ro = oracle.recommend(users, csr.offsets, csr.items, n_rec, True, *args)
+    assert not np.isnan(rec).any()
+    assert set(rec[0].astype(int)) <= set(unseen.tolist()) and len(set(rec[0].astype(int))) == n_rec
+    assert np.array_equal(rec, ro)

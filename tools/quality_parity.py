@@ -36,6 +36,9 @@ ap.add_argument("--metrics", default="hit,mrr,prec,rec")
 a = ap.parse_args()
 
 rows = []
+T0 = time.time()
+
+
 def engine_of(variant, **kw):
     tune = {x.split("=")[0]: int(x.split("=")[1]) for x in variant.split(",") if "=" in x}
     return EngineOptions(negative_stripes="nostripes" not in variant.split(","), tune=tune, **kw)
@@ -45,6 +48,7 @@ for seed in range(a.seed0, a.seed0 + a.seeds):
     d = (synthetic.make_planted_large(a.users, a.items, seed=seed, mean_degree=a.degree) if a.large
          else synthetic.make_planted(a.users, a.items, seed=seed, n_tags=a.tags))
     train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
+    print("seed %d: data ready, %d train rows (%.0f s since start)" % (seed, len(train), time.time() - T0), flush=True)
     uf = itf = None
     if a.tags:
         uf = pd.concat([pd.DataFrame({"u": np.arange(a.users)}), pd.DataFrame(d["user_tags"])], axis=1)
@@ -71,6 +75,7 @@ for seed in range(a.seed0, a.seed0 + a.seeds):
         fns = dict(hit=evaluation.hit_rate, mrr=evaluation.reciprocal_rank, prec=evaluation.precision, rec=evaluation.recall)
         res[side] = dict({k: fns[k](m, test, k=10) for k in a.metrics.split(",")},
                          nvu=np.linalg.norm(m.v_u), nvi=np.linalg.norm(m.v_i), nwi=np.linalg.norm(m.w_i), t=dt)
+        print("  seed %d side %-32s %s   (%.0f s since start)" % (seed, side, {k: round(float(v), 4) for k, v in res[side].items()}, time.time() - T0), flush=True)
     rows.append(res)
     print("seed %d  n_train %d" % (seed, len(train)), {s: {k: round(float(v), 4) for k, v in r.items()} for s, r in res.items()}, flush=True)
 for side in [s for s in rows[0] if s != "oracle"]:
