@@ -116,6 +116,9 @@ def strong_scaling_record(world, rank, device, steps, warmup, barrier):
 
 
 def main():
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, all_threads=True)      # `timeout -s USR1 ...` shows where a stuck run is waiting
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

@@ -560,8 +560,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // Hot rows: items that >= kHotMin in-flight updates would touch at once (estimated with the default geometry).  Their
     // atomics serialise on one or two cache lines -- on BASELINE config 2 the ten hottest items cost half the epoch -- so
     // the HOT kernel accumulates them per workgroup in LDS.  (bit 2 of debug_flags switches this off.)
+    // (models with features: only the pipelined row loop of sgd_features_kernel carries the accumulators -- BPR, 16-lane row groups,
+    //  at most 32 + 32 features)
+    const bool feat_fast = feat && shape->group == 16 && cfg->max_samples == 1 && cfg->n_user_features <= 32 && cfg->n_item_features <= 32;
     std::vector<int> hot_order;
-    if (damp && build_plan && use_segments && !feat && !(cfg->debug_flags & 4)) {
+    if (damp && build_plan && use_segments && (!feat || feat_fast) && !(cfg->debug_flags & 4)) {
         const double g0 = (double)(g_sm_count > 0 ? g_sm_count : 256) * 16.0 * (64 / shape->group);
         const double kHotMin = 16.0;
         for (int i = 0; i < cfg->n_items; ++i)
@@ -572,7 +575,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         if ((int)hot_order.size() > max_hot) hot_order.resize(max_hot > 0 ? max_hot : 0);
         n_hot = (int)hot_order.size();
     }
-    const bool use_hot = use_segments && !feat && !single_group && n_hot > 0;
+    const bool use_hot = use_segments && (!feat || feat_fast) && !single_group && n_hot > 0;
     // Negative stripes (rfm_sgd.hpp, STRIPE; include/rfm_rng.h): the production path without features.  debug_flags bit 3 falls back to whole-catalogue draws with one set of atomics per negative.
     // BPR only: WARP's candidate screening inside a stripe (up to 50 draws WITH replacement from ~200 items) changes the
     // statistics of the rank estimate -- against the sequential oracle the log-likelihood moved by -5 % at a 12-row window --
@@ -586,7 +589,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // kernel the parity tests pin to the oracle.  Undamped Hogwild on skewed data needs every push published at once: notes.)
     const bool use_stripes = want_stripes && use_segments;
     const sgd_launch_fn launch = use_stripes ? shape->table()[10 + (fresh ? 1 : 0) + (use_hot ? 2 : 0)]
-                                 : use_hot  ? shape->table()[8 + (fresh ? 1 : 0)]
+                                 : (use_hot && !feat) ? shape->table()[8 + (fresh ? 1 : 0)]
                                  : use_segments ? shape->table()[4 + (feat ? 1 : 0) + (fresh ? 2 : 0)]
                                                 : shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
 

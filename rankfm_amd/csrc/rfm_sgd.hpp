@@ -1429,8 +1429,9 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                 if (threadIdx.x == 0) {
                     int stop = 0;
                     for (unsigned spin = 0;; ++spin) {
-                        if (NP > 0 && flag_load(flags + kFeatReady + 2 * p + par) >= m + 1u) break;
+                        // (the row loops' end is checked FIRST: the producers stay ahead of the trainer, so a batch is always ready)
                         if (flag_load(flags + kFeatDone) >= (unsigned)n_regular) { stop = 1; break; }
+                        if (NP > 0 && flag_load(flags + kFeatReady + 2 * p + par) >= m + 1u) break;
                         if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }      // (never observed: a hang guard)
                         __builtin_amdgcn_s_sleep(8);
                     }
@@ -1582,7 +1583,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
         lds_float *t_uf = lds, *t_if = lds + (size_t)P8 * FS, *t_wif = lds + (size_t)(P8 + Q8) * FS;
         const int n_fast = (P8 + Q8) * FS + a.n_if;
         // LDS element e of the lane-major copy <- table element (global), or zero padding
-        auto refresh = [&](int e) {
+        auto table_elem = [&](int e) {
             float v = 0.0f;
             if (e < (P8 + Q8) * FS) {
                 const int r = e / FS, w = e % FS, f = (w % KPL) * G + w / KPL;     // lane w / KPL, its dword w % KPL
@@ -1591,9 +1592,19 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                     else if (r - P8 < a.n_if) v = __hip_atomic_load(a.v_if + (size_t)(r - P8) * F + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             } else v = __hip_atomic_load(a.w_if + (e - (P8 + Q8) * FS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            lds_tables[e] = v;
+            return v;
         };
-        for (int e = threadIdx.x; e < n_fast; e += blockDim.x) refresh(e);
+        for (int e = threadIdx.x; e < n_fast; e += blockDim.x) lds_tables[e] = table_elem(e);
+        // hot positive items (SgdArgs::hot_item): pending updates of this workgroup in 32-bit fixed point, behind the tables
+        const int hot_off = (n_fast + 3) & ~3, n_hot = a.n_hot;
+        lds_int *hot_acc = (lds_int *)(lds + hot_off), *hot_accw = hot_acc + n_hot * F;
+        for (int k = threadIdx.x; k < n_hot * (F + 1); k += blockDim.x) hot_acc[k] = 0;
+        float hot_scale = 16777216.0f, hot_unit = 1.0f / 16777216.0f;
+        if (n_hot > 0) {
+            const float range = fmaxf(1.0f, __uint_as_float(*a.sw_max_bits) * a.eta * 10.0f);      // (see RowStep::kHotScale)
+            hot_scale = 16777216.0f / range;
+            hot_unit = range / 16777216.0f;
+        }
         __syncthreads();
         typedef RowStep<G, KPL, false, true, true, FRESH, true, false, false, false, 0> Reg;
         Reg step(a, sub, lds, lds, lds);                               // (draws, membership test, user damping; its tables are unused)
@@ -1638,12 +1649,24 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
             return x;
         };
         for (int iter = 0; __any(active); ++iter) {
-            // every wavefront refreshes its slice of the workgroup's copy on every row (readers may see a row half old, half new: both
-            // are tables the trainer published)
+            // Every wavefront keeps a slice of the workgroup's copy fresh, a part of it per row: the loads are issued here and land in
+            // LDS at the END of the row, so that their latency (system-scope loads go to memory) is the row's, not an extra round
+            // trip.  (Readers may see a row half old, half new: both are tables the trainer published.)
+            constexpr int RF = 2;
+            float rf_val[RF];
+            int rf_e[RF];
             if (trains) {
                 const int per = (n_fast + n_waves - 1) / n_waves, e0 = wave * per, e1 = e0 + per < n_fast ? e0 + per : n_fast;
-                for (int e = e0 + lane; e < e1; e += 64) refresh(e);
+                const int parts = (per + 64 * RF - 1) / (64 * RF);
+#pragma unroll
+                for (int k = 0; k < RF; ++k) {
+                    rf_e[k] = e0 + lane + 64 * ((iter % parts) * RF + k);
+                    rf_val[k] = rf_e[k] < e1 ? table_elem(rf_e[k]) : 0.0f;
+                    if (rf_e[k] >= e1) rf_e[k] = -1;
+                }
             }
+            if (n_hot > 0 && !a.hot_direct && iter % n_waves == wave)          // bin sweeping duty (SgdArgs::hot_bins_v)
+                for (int line = blockIdx.x; line < hot_lines(a); line += gridDim.x) hot_sweep_line(a, line);
             if (active && !have) {
                 const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
                 const int4 d = a.seg_desc[seg];
@@ -1684,6 +1707,16 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                 if (a.single_group) fetch_pos(i, cur);
                 else if (t + 1 < len) fetch_pos(__shfl(pick(seg_item, t + 1), lane_base + (int)((unsigned)(t + 1) % G)), nxt);   // overlaps this row
                 const uint32_t row_key = rfm_row_key(a.epoch_key, (uint32_t)pos);
+                // a hot positive item: the workgroup's own pending updates of its row are part of the view (RowStep, HOT)
+                int slot = -1;
+                if (n_hot > 0 && cur.scale >= 2.0f) {
+                    slot = (int)(cur.scale * 0.5f) - 1;
+                    cur.scale -= 2.0f * (float)(slot + 1);
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (sub + G * k < F) cur.v[k] += (float)hot_acc[slot * F + sub + G * k] * hot_unit;
+                    cur.w += (float)hot_accw[slot] * hot_unit;
+                }
                 // the negative (:250-253) and its gathers
                 uint32_t attempt = 0;
                 int srow_unused;
@@ -1728,11 +1761,32 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                     const float d_i = eta_i * (g * (d_outer * g_i) - reg_a * cur.v[k]);               // :309
                     const float d_j = eta * (g * (d_outer * -g_i) - reg_a * vj[k]);                   // :310
                     vu[k] += d_u;
-                    if (sub + G * k < F) { atomic_add_f32(pi + G * k, d_i); atomic_add_f32(pj + G * k, d_j); }
+                    if (sub + G * k < F) {
+                        if (slot >= 0) __hip_atomic_fetch_add(hot_acc + slot * F + sub + G * k, __float2int_rn(d_i * hot_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else atomic_add_f32(pi + G * k, d_i);
+                        atomic_add_f32(pj + G * k, d_j);
+                    }
                 }
                 if (sub == 0) {
-                    atomic_add_f32(a.w_i + (size_t)i * a.w_stride, eta_i * (g * (d_outer * 1.0f) - reg_a * cur.w));    // :279
+                    const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * cur.w);                                  // :279
+                    if (slot >= 0) __hip_atomic_fetch_add(hot_accw + slot, __float2int_rn(dwi * hot_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else atomic_add_f32(a.w_i + (size_t)i * a.w_stride, dwi);
                     atomic_add_f32(a.w_i + (size_t)j * a.w_stride, eta * (g * (d_outer * -1.0f) - reg_a * wj));        // :280
+                }
+                // every hot_period-th toucher of a slot publishes what the workgroup has accumulated for it (a keyed coin, RowStep)
+                if (slot >= 0 && __umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)a.hot_period[slot]) == 0u) {
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k) {
+                        if (sub + G * k >= F) continue;
+                        const float d = (float)__hip_atomic_exchange(hot_acc + slot * F + sub + G * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * hot_unit;
+                        if (d != 0.0f)
+                            atomic_add_f32(a.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
+                                                        : a.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * n_hot + slot) * F + sub + G * k, d);
+                    }
+                    if (sub == 0) {
+                        const float d = (float)__hip_atomic_exchange(hot_accw + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * hot_unit;
+                        if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)i * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * n_hot + slot, d);
+                    }
                 }
                 if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next row reads what this one wrote
                 if (++t == len) {
@@ -1744,6 +1798,23 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                     sp += stride;
                     active = sp < a.pos_end;
                 }
+            }
+            if (trains) {
+#pragma unroll
+                for (int k = 0; k < RF; ++k)
+                    if (rf_e[k] >= 0) lds_tables[rf_e[k]] = rf_val[k];
+            }
+        }
+        if (n_hot > 0) {          // publish whatever is still pending
+            __syncthreads();
+            for (int k = threadIdx.x; k < n_hot * F; k += blockDim.x) {
+                const float d = (float)hot_acc[k] * hot_unit;
+                if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.v_i + (size_t)a.hot_item[k / F] * F + (k % F)
+                                                           : a.hot_bins_v + (size_t)(blockIdx.x % kHotBins) * n_hot * F + k, d);
+            }
+            for (int k = threadIdx.x; k < n_hot; k += blockDim.x) {
+                const float d = (float)hot_accw[k] * hot_unit;
+                if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * n_hot + k, d);
             }
         }
         if (trains) {

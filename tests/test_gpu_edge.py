@@ -82,7 +82,7 @@ def test_heavy_user_spans_many_segments(oracle):
     # full Hogwild on the same data stays finite and close (the heavy user's concurrent segments are damped)
     g, rep, o, out = _run(pairs, csr, sw, 32, 1, 3, 11, {}, oracle)
     assert all(np.isfinite(g[k]).all() for k in WEIGHTS)
-    np.testing.assert_allclose(rep["log_likelihood"], out["ll"], rtol=0.03)
+    np.testing.assert_allclose(rep["log_likelihood"], out["ll64"], rtol=0.03)
     assert abs(np.linalg.norm(g["v_i"]) - np.linalg.norm(o["v_i"])) < 0.03 * np.linalg.norm(o["v_i"])
 
 
