@@ -15,8 +15,9 @@ resident in HBM when the timed region starts.
 Prints ONE JSON line (rank 0) with the driver's contract fields plus:
   roofline     achieved = algorithmic bytes (24F+32 = 1568 B per update) x rows per launch / average
                HIP-event duration of the SGD kernel launch, against the 8 TB/s HBM3E peak; `peak_measured` = what a plain
-               streaming kernel gets from this box's HBM (rfm_hbm_probe), `frac_whole_catalogue` = the same fraction for the
-               kernel with the reference's sampler (every negative drawn from the whole catalogue, no negative stripes)
+               streaming kernel gets from this box's HBM (rfm_hbm_probe).  The timed kernel draws its negatives like the
+               reference (uniformly over the whole catalogue); `frac_negative_stripes` = the same fraction with the OPT-IN stripe
+               sampler (EngineOptions.negative_stripes: faster, but measurably worse ranking quality -- not the default)
   cpu_baseline the CPU restatement of the reference's `_fit` (oracle/, "port"; MT19937 + linear membership scan like
                the reference) timed on ONE host core (the reference is single-threaded) on a bounded sample
 """
@@ -137,6 +138,7 @@ def main():
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
     ap.add_argument("--weak", action="store_true", help="configs 4 / 5: weak scaling (every rank its own config-sized shard)")
     ap.add_argument("--learning-rate", type=float, default=0.0, help="override the config's learning rate")
+    ap.add_argument("--negative-stripes", action="store_true", help="time the opt-in stripe sampler instead of the reference's uniform one")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sub-record (config 4 sharded over the ranks)")
     ap.add_argument("--tune", default="", help="geometry overrides of rfm_fit_config (experiments): 'stripe_window=12,segment_rows=32'")
     args = ap.parse_args()
@@ -207,7 +209,8 @@ def main():
                                         syncs_per_epoch=args.syncs_per_epoch, seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
                                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
                                         shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check,
-                                        tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv})
+                                        tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv},
+                                        negative_stripes=args.negative_stripes)
     broadcast_from_rank0([trainer.shared.flat])
 
     def barrier():
@@ -269,8 +272,9 @@ def main():
                        "(stripes tile a keyed permutation of the catalogue, every item offered equally often), user segments <= %d rows"
                        % (geo["stripe_window"], geo["stripe_rows"], geo.get("segment_rows", 32)))
         else:
-            sampler = "negatives drawn uniformly over the whole catalogue (the reference's sampler), user segments <= %d rows" % (geo.get("segment_rows") or 32)
-        peak_measured = frac_whole = k_ms_whole = None
+            sampler = "negatives drawn uniformly over the whole catalogue (the reference's sampler, rankfm/_rankfm.pyx:250-253), user segments <= %d rows" % (geo.get("segment_rows") or 32)
+        peak_measured = frac_other = k_ms_other = None
+        other_name = "whole_catalogue" if args.negative_stripes else "negative_stripes"
         if world == 1:
             import ctypes as C
             from rankfm_amd import _hip
@@ -278,16 +282,17 @@ def main():
             if _hip.lib().rfm_hbm_probe(C.c_size_t(2 << 30), 5, C.byref(rd), C.byref(cp)) == 0:
                 peak_measured = {"read": rd.value, "copy": cp.value, "unit": "GB/s",
                                  "how": "rfm_hbm_probe: 16 B/lane streaming kernel over 2 GiB, best of 5 launches (copy = read + write bytes)"}
-            if geo.get("stripe_rows", 0) > 0:
-                # the same workload with the reference's sampler (debug_flags bit 3): continues from the trained weights
+            if cfg["max_samples"] == 1 and not (n_uf or n_if):
+                # the same workload with the OTHER sampler (the opt-in stripes when the timed run used the reference's uniform draws,
+                # and the other way round): continues from the trained weights
                 from rankfm_amd.engine import DeviceSession
-                plain = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"], shard["x_uf"], x_if,
-                                      {k: v.clone() for k, v in sess.weights.items()}, device=device, seed=1492, debug_flags=args.debug_flags | 8,
-                                      hogwild_damping=args.damping, check_finite=not args.no_check, **hyper)
-                plain.run(epochs=2, epoch_begin=epoch)
-                k_ms_whole = float(np.mean(plain.run(epochs=5, epoch_begin=epoch + 2)["sgd_kernel_ms"]))
-                frac_whole = bytes_per_update * N / (k_ms_whole * 1e-3) / 1e9 / HBM_PEAK_GBPS
-                del plain
+                other = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"], shard["x_uf"], x_if,
+                                      {k: v.clone() for k, v in sess.weights.items()}, device=device, seed=1492, debug_flags=args.debug_flags,
+                                      negative_stripes=not args.negative_stripes, hogwild_damping=args.damping, check_finite=not args.no_check, **hyper)
+                other.run(epochs=2, epoch_begin=epoch)
+                k_ms_other = float(np.mean(other.run(epochs=5, epoch_begin=epoch + 2)["sgd_kernel_ms"]))
+                frac_other = bytes_per_update * N / (k_ms_other * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                del other
         out = {
             "metric": "(user,item,neg) pairwise updates/sec at k=64; achieved HBM GB/s vs peak",
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -306,7 +311,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "peak_measured": peak_measured,
-                         "frac_whole_catalogue": frac_whole, "kernel_ms_whole_catalogue": k_ms_whole,
+                         "frac_" + other_name: frac_other, "kernel_ms_" + other_name: k_ms_other,
                          "kernel": "rfm::sgd_features_kernel" if (n_uf or n_if) else "rfm::sgd_segments_kernel", "kernel_ms_per_launch": k_ms,
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }

@@ -63,6 +63,13 @@ typedef enum rfm_status {
 #define RFM_MODE_SERIAL 1   /* one wavefront walks the shuffled rows in order with plain read-modify-write:
                                the reference's sequential semantics (parity / debugging mode) */
 
+/* negative sampler */
+#define RFM_SAMPLER_UNIFORM 0   /* the reference's: every draw uniform over the whole catalogue (rankfm/_rankfm.pyx:250-253).  Default. */
+#define RFM_SAMPLER_STRIPES 1   /* opt-in, BPR Hogwild launches that fill the chip: a workgroup draws the negatives of a window of rows
+                                   from a stripe of items it holds in LDS and publishes their updates once per window.
+                                   ~1.5x the update rate, but NOT the reference's sampler: measured cost 1.0 point of hit_rate@10 at
+                                   30 k x 12 k and 2.3 points at 100 k x 50 k planted problems (profiles/r03_notes.md). */
+
 /* negative-draw stream */
 #define RFM_RNG_MT19937 0   /* reference stream: MT19937, `% I` (serial mode only; needs explicit perms) */
 #define RFM_RNG_COUNTER 1   /* counter-based draws keyed by (seed, epoch, row, attempt): include/rfm_rng.h */
@@ -103,7 +110,7 @@ typedef struct rfm_fit_config {
     int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
                                       bit 1: factor-row loads bypass the per-CU L1,
                                       bit 2: no LDS accumulation of hot item rows,
-                                      bit 3: no negative stripes (draws over the whole catalogue, atomics per negative),
+                                      bit 3: no negative stripes even when `sampler` asks for them,
                                       bit 4: negative stripes for WARP as well (experiments; BPR only by default),
                                       bit 5: models with features: the dense feature tables are NOT trained (no table trainer); with
                                              bit 0 the row loop of the features kernel runs on one row group -- parity tests */
@@ -124,7 +131,8 @@ typedef struct rfm_fit_config {
     int32_t tune_feature_waves;    /* wavefronts per workgroup of the features kernel, 2..16 (auto: 16) */
     int32_t tune_table_producers;      /* features kernel: step-producer workgroups feeding the table trainer, 1..16 (auto: one per
                                       16 row-loop workgroups, at most 12) */
-    int32_t tune_reserved[2];      /* must be 0 */
+    int32_t sampler;               /* RFM_SAMPLER_* (0 = the reference's uniform sampler) */
+    int32_t tune_reserved[1];      /* must be 0 */
 } rfm_fit_config;
 
 /* All pointers of one struct live in the same memory space: device memory for the *_device entry

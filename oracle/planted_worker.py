@@ -1,0 +1,24 @@
+"""Test infrastructure: one seed of a planted ranking problem and the sequential oracle's fit on it, as a picklable task for a
+process pool (the quality tests farm their seeds out: data generation and the oracle are CPU work, the GPU side stays in the test
+process).  Never imported by the product."""
+import numpy as np
+
+
+def fit_planted(args):
+    """(seed, n_users, n_items, factors, epochs) -> dict(train, test, oracle weights); the oracle starts from the weights
+    `np.random.seed(seed); RankFM(...)._init_all(train)` draws -- what the engine side of the test starts from as well -- and
+    draws its negatives like the reference: uniformly over the whole catalogue (counter RNG, its own keyed visiting order)"""
+    import pandas as pd
+    from oracle import oracle as orc
+    from rankfm_amd import EngineOptions, RankFM, synthetic
+    seed, n_users, n_items, factors, epochs = args
+    orc.build()
+    d = synthetic.make_planted(n_users, n_items, seed=seed)
+    train = pd.DataFrame(d["train"], columns=["u", "i"])
+    m = RankFM(factors=factors, loss="bpr", engine=EngineOptions(seed=100 + seed))
+    np.random.seed(seed)
+    m._init_all(train)
+    orc.fit(m.interactions, m.sample_weight, m.user_items.offsets, m.user_items.items, m.x_uf, m.x_if, m.w_i, m.w_if, m.v_u, m.v_i, m.v_uf,
+            m.v_if, m.alpha, m.beta, m.learning_rate, m.learning_schedule, m.learning_exponent, 1, epochs, perms=None,
+            rng_mode=orc.RNG_COUNTER, seed=100 + seed, membership="binary")
+    return dict(seed=seed, train=d["train"], test=d["test"], weights={k: getattr(m, k) for k in ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")})

@@ -17,6 +17,7 @@ ERR_NONFINITE = 100
 SCHEDULE_CONSTANT, SCHEDULE_INVSCALING = 0, 1
 MODE_HOGWILD, MODE_SERIAL = 0, 1
 RNG_MT19937, RNG_COUNTER = 0, 1
+SAMPLER_UNIFORM, SAMPLER_STRIPES = 0, 1
 REFERENCE_MT_SEED = 1492       # rankfm/_rankfm.pyx:182
 
 
@@ -38,7 +39,7 @@ class FitConfig(C.Structure):
         ("plan_token", C.c_int64),
         ("tune_segment_rows", C.c_int32), ("tune_stripe_window", C.c_int32), ("tune_stripe_rows", C.c_int32),
         ("tune_hot_publications", C.c_int32), ("tune_feature_waves", C.c_int32), ("tune_table_producers", C.c_int32),
-        ("tune_reserved", C.c_int32 * 2),
+        ("sampler", C.c_int32), ("tune_reserved", C.c_int32 * 1),
     ]
 
 

@@ -261,7 +261,8 @@ static int validate(const rfm_fit_config *c) {
         return RFM_ERR_UNKNOWN_SCHEDULE;
     if (c->mode != RFM_MODE_HOGWILD && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;
     if (c->tune_segment_rows < 0 || c->tune_segment_rows > kSegmentRows || c->tune_stripe_window < 0 || c->tune_stripe_rows < -1 ||
-        c->tune_hot_publications < 0 || c->tune_feature_waves < 0 || c->tune_table_producers < 0 || c->tune_reserved[0] || c->tune_reserved[1])
+        c->tune_hot_publications < 0 || c->tune_feature_waves < 0 || c->tune_table_producers < 0 || c->tune_reserved[0] ||
+        (c->sampler != RFM_SAMPLER_UNIFORM && c->sampler != RFM_SAMPLER_STRIPES))
         return RFM_ERR_BAD_ARG;
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
     if (c->rng == RFM_RNG_MT19937 && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;   // one serial stream
@@ -494,7 +495,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // used -- decided here, before the plan, from everything the later `use_stripes` depends on except the plan itself.
     const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
     const bool one_group_flag = (cfg->debug_flags & 1) != 0;
-    bool want_stripes = use_segments && !feat && !(cfg->debug_flags & 8) &&
+    bool want_stripes = use_segments && !feat && cfg->sampler == RFM_SAMPLER_STRIPES && !(cfg->debug_flags & 8) &&
                         (cfg->max_samples == 1 || (cfg->debug_flags & 16)) && cfg->n_factors == shape->group * shape->kpl &&
                         (one_group_flag || (damp_m > 0.0f && N > 0));
     if (want_stripes && !one_group_flag && cfg->n_workgroups <= 0) {
@@ -787,7 +788,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.max_groups = max_groups;
         a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
         a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w; a.sw_max_bits = ws.sw_max_bits;
-        a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * grid ? 1 : 0;   // see SgdArgs::hot_bins_v
+        // (sweeping workgroups: all of them, or the row-loop workgroups of the features kernel)
+        a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * (grid - (n_producers > 0 ? 1 + n_producers : 0)) ? 1 : 0;   // see SgdArgs::hot_bins_v
         a.stripe_rows = stripe_rows; a.stripe_window = stripe_window;
         a.item_bits = rfm_perm_bits((uint32_t)cfg->n_items);
         a.launch_index = 0;
@@ -894,8 +896,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->waves_per_launch = single_group ? 1 : grid * waves_per_block;
         rep->workgroups = grid;
         rep->groups_per_workgroup = single_group ? 1 : waves_per_block * groups_per_wave;
-        rep->working_groups = single_group ? 1 : ((max_groups > 0 && max_groups < (int64_t)grid * waves_per_block * groups_per_wave)
-                                                      ? max_groups : (int64_t)grid * waves_per_block * groups_per_wave);
+        // (row-loop groups: the trainer and the producers of the features kernel do not train rows)
+        const int64_t row_groups = (int64_t)(grid - (n_producers > 0 ? 1 + n_producers : 0)) * waves_per_block * groups_per_wave;
+        rep->working_groups = single_group ? 1 : ((max_groups > 0 && max_groups < row_groups) ? max_groups : row_groups);
         rep->units_per_launch = units_per_launch;
         rep->n_units = units;
         rep->stripe_rows = stripe_rows;

@@ -1665,8 +1665,10 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                     if (rf_e[k] >= e1) rf_e[k] = -1;
                 }
             }
-            if (n_hot > 0 && !a.hot_direct && iter % n_waves == wave)          // bin sweeping duty (SgdArgs::hot_bins_v)
-                for (int line = blockIdx.x; line < hot_lines(a); line += gridDim.x) hot_sweep_line(a, line);
+            // bin sweeping duty (SgdArgs::hot_bins_v).  The lines are owned by the ROW-LOOP workgroups only: the trainer and the producers
+            // never come here, and a line nobody sweeps -- the first lines are the hottest items' -- would stay unpublished all launch
+            if (n_hot > 0 && !a.hot_direct && iter % n_waves == wave)
+                for (int line = (int)blockIdx.x - first_regular; line < hot_lines(a); line += n_regular) hot_sweep_line(a, line);
             if (active && !have) {
                 const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
                 const int4 d = a.seg_desc[seg];

@@ -19,7 +19,7 @@ class DeviceSession:
                  learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25, max_samples=1,
                  mode="hogwild", rng="counter", seed=1492, device=None, n_workgroups=0, rows_per_launch=0,
                  check_finite=True, want_penalty=False, has_user_features=None, has_item_features=None,
-                 shape_override=0, hogwild_damping=0.0, debug_flags=0, tune=None):
+                 shape_override=0, hogwild_damping=0.0, debug_flags=0, tune=None, negative_stripes=False):
         if not torch.cuda.is_available():
             raise _hip.EngineUnavailable("no MI355X visible to PyTorch-ROCm: rankfm_amd has no CPU fallback")
         _hip.lib()
@@ -64,6 +64,7 @@ class DeviceSession:
         self.hogwild_damping = float(hogwild_damping)
         self._plan_token = 0
         self.debug_flags = int(debug_flags)
+        self.sampler = _hip.SAMPLER_STRIPES if negative_stripes else _hip.SAMPLER_UNIFORM      # (see EngineOptions.negative_stripes)
         self.tune = _hip.tune_kwargs(tune)       # geometry overrides (experiments); part of the plan, so fixed per session
         self._geometry = None
 
@@ -71,7 +72,7 @@ class DeviceSession:
         return _hip.FitConfig(
             rng_epoch_offset=int(rng_epoch_offset),
             epoch_part_index=part[0] if part else 0, epoch_parts=part[1] if part else 0,
-            hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token), debug_flags=self.debug_flags,
+            hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token), debug_flags=self.debug_flags, sampler=self.sampler,
             debug_update_mode=0, debug_shape=self.shape_override,
             n_interactions=self.n_interactions, n_users=self.n_users, n_items=self.n_items,
             n_user_features=self.n_user_features, n_item_features=self.n_item_features, n_factors=self.n_factors,
@@ -126,6 +127,24 @@ class DeviceSession:
     def geometry(self):
         """launch geometry of the last run (what rankfm_amd.order needs to mirror the engine's draws on the host)"""
         return self._geometry
+
+    def step_scales(self):
+        """The Hogwild step damping of the last run's plan as two arrays: the scale of the positive item's step per item [I] and of
+        the user's step per user [U] (both 1 where nothing is damped).  Diagnostic: the sequential oracle can apply the same scales
+        (its `pos_step` / `user_step`), which separates what the damping changes -- a deliberate change of the optimiser -- from what
+        asynchronous execution changes.  Read from the plan at the head of the workspace (rfm_api.hip `carve`: pos_scale [I] comes
+        first, a hot slot s is encoded as scale + 2 (s + 1)) and the launch geometry (user_cap = M x segments / interactions in
+        flight, rfm_api.hip "plan, part 3")."""
+        g = self._geometry
+        m = 128.0 if self.hogwild_damping == 0 else self.hogwild_damping
+        if self._workspace is None or g is None or m <= 0 or g.get("single_group") or self.mode == _hip.MODE_SERIAL:
+            return np.ones(self.n_items, np.float32), np.ones(self.n_users, np.float32)
+        raw = self._workspace[:4 * self.n_items].view(torch.float32).cpu().numpy().astype(np.float64)
+        slot = np.where(raw >= 2.0, np.floor(raw * 0.5), 0.0)
+        pos = (raw - 2.0 * slot).astype(np.float32)
+        user_cap = m * float(g["n_units"]) / float(g["working_groups"])
+        deg = np.maximum(np.diff(self.csr_offsets.cpu().numpy()), 1)
+        return pos, np.minimum(1.0, user_cap / deg).astype(np.float32)
 
     def weights_to_host(self):
         return {k: v.detach().cpu().numpy() for k, v in self.weights.items()}

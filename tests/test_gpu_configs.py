@@ -6,7 +6,9 @@ item catalogue) -- runs at full size here, against the sequential CPU oracle whe
 through size-independent properties where it does not.
 
 Every comparison with the oracle is on the engine's own visiting order and counter-based draws (rankfm_amd.order), like the
-config-2 test; tolerances are stated per check and are statistical by construction (Hogwild).
+config-2 test; tolerances are stated per check and are statistical by construction (Hogwild).  Log-likelihoods are compared with
+the oracle's DOUBLE sum (`ll64`: the reference's float accumulator is off by +0.4 % on config 3 and -1.7 % on config 4's share,
+profiles/r03_notes.md).
 """
 import numpy as np
 import pytest
@@ -18,7 +20,7 @@ def _norm_ratio(a, b):
     return float(np.linalg.norm(a) / np.linalg.norm(b))
 
 
-def _oracle_epoch(oracle, sh, w, max_samples, epoch, seed, lr, geometry=None):
+def _oracle_epoch(oracle, sh, w, max_samples, epoch, seed, lr, geometry=None, **oracle_kw):
     """one epoch of the sequential oracle, in place on `w`, in the engine's order of epoch `epoch`"""
     from rankfm_amd import order
     pairs = sh["interactions"]
@@ -29,12 +31,13 @@ def _oracle_epoch(oracle, sh, w, max_samples, epoch, seed, lr, geometry=None):
     perms = order.epoch_positions(sh["csr_offsets"], seed, epoch, (geometry or {}).get("segment_rows") or None)[None, :].astype(np.int32)
     return oracle.fit(pairs_csr, sw_csr, sh["csr_offsets"], sh["csr_items"], sh["x_uf"], sh["x_if"], w["w_i"], w["w_if"], w["v_u"],
                       w["v_i"], w["v_uf"], w["v_if"], 0.01, 0.1, lr, "constant", 0.25, max_samples, 1, perms=perms,
-                      rng_mode=oracle.RNG_COUNTER, seed=seed, membership="binary", epoch_begin=epoch, want_negatives=True,
+                      rng_mode=oracle.RNG_COUNTER, seed=seed, membership="binary", epoch_begin=epoch, want_negatives=True, **oracle_kw,
                       **order.oracle_stripes(sh["csr_offsets"], seed, [epoch], geometry, len(w["w_i"])))
 
 
-def _trained_then_one_epoch(oracle, sh, max_samples, warm_epochs, seed, lr=0.1):
-    """`warm_epochs` epochs on the GPU, then ONE more epoch on the GPU and on the oracle from the same trained weights"""
+def _trained_then_one_epoch(oracle, sh, max_samples, warm_epochs, seed, lr=0.1, damped=False):
+    """`warm_epochs` epochs on the GPU, then ONE more epoch on the GPU and on the oracle from the same trained weights; with `damped`
+    also on the oracle under the engine's step damping (returned last)"""
     from rankfm_amd.engine import DeviceSession
     sess = DeviceSession(sh["interactions"], sh["sample_weight"], sh["csr_offsets"], sh["csr_items"], sh["x_uf"], sh["x_if"],
                          sh["weights"], max_samples=max_samples, seed=seed, learning_rate=lr)
@@ -44,6 +47,11 @@ def _trained_then_one_epoch(oracle, sh, max_samples, warm_epochs, seed, lr=0.1):
     g = sess.weights_to_host()
     o = {k: v.copy() for k, v in w0.items()}
     out = _oracle_epoch(oracle, sh, o, max_samples, warm_epochs, seed, lr, sess.geometry())
+    if damped:
+        pos_step, user_step = sess.step_scales()
+        od = {k: v.copy() for k, v in w0.items()}
+        outd = _oracle_epoch(oracle, sh, od, max_samples, warm_epochs, seed, lr, sess.geometry(), pos_step=pos_step, user_step=user_step)
+        return w0, g, rep, o, out, warm, (od, outd)
     return w0, g, rep, o, out, warm
 
 
@@ -54,7 +62,7 @@ def _assert_epoch_tracks_oracle(w0, g, rep, o, out, names, norm_tol, ll_tol, del
         # the epoch's MOVE of every weight, not the weights (which share their starting point)
         c = np.corrcoef((g[k] - w0[k]).ravel(), (o[k] - w0[k]).ravel())[0, 1]
         assert c > delta_corr, "%s: correlation of the epoch's updates with the sequential oracle's %.4f" % (k, c)
-    np.testing.assert_allclose(rep["log_likelihood"], out["ll"], rtol=ll_tol)
+    np.testing.assert_allclose(rep["log_likelihood"], out["ll64"], rtol=ll_tol)
     if draws_tol is not None:
         np.testing.assert_allclose(float(rep["n_draws"][0]), float(out["nsamp"].sum()), rtol=draws_tol)
 
@@ -62,21 +70,28 @@ def _assert_epoch_tracks_oracle(w0, g, rep, o, out, names, norm_tol, ll_tol, del
 def test_config3_full_size_warp_tracks_sequential_oracle(oracle, c2_problem):
     """BASELINE config 3 = config 2's data, loss='warp', max_samples=50, at FULL size (rankfm/_rankfm.pyx:244-270).  Three
     epochs of training first, so that the model is past the stage where every first draw violates the margin: the compared
-    epoch evaluates several candidates per update (the count is printed and checked against the oracle's).  Norms 2 %,
-    log-likelihood 2 %, accepted draws 5 %, correlation of the epoch's weight updates with the oracle's > 0.8 (WARP's discrete
-    decisions -- first violating draw, rank-dependent multiplier -- turn stale reads into different-but-equivalent steps: the
-    same allowance test_hogwild_warp_statistical_parity makes)."""
+    epoch evaluates several candidates per update (the count is printed and checked against the oracle's).  Two comparisons of
+    that epoch, from the same weights, on the engine's order and draws:
+      (a) the sequential oracle under the ENGINE'S STEP DAMPING (hot items' and heavy users' steps scaled like the plan scales
+          them, DeviceSession.step_scales): what is left is asynchronous execution alone -- log-likelihood 1 %, accepted draws
+          1.5 %, norms 1 % (measured +0.15 %, -0.23 %, <= 0.2 %);
+      (b) the reference's algorithm itself: log-likelihood 2.75 %, draws 5 %, |v_u|, |v_i| 2 %, |w_i| 4 % (measured +1.91 ... +1.93 %,
+          -3.7 %, -0.06 / -0.32 %, +2.66 % in six runs -- i.e. almost all of it is the damping, a deliberate change of the
+          optimiser that keeps the Zipf head from overshooting: DESIGN.md section 5).
+    Correlation of the epoch's weight updates with the oracle's > 0.8 (WARP's discrete decisions -- first violating draw,
+    rank-dependent multiplier -- turn stale reads into different-but-equivalent steps)."""
     U, I, N, F, pairs, csr = c2_problem
     from rankfm_amd import synthetic
     sh = dict(interactions=pairs, sample_weight=np.ones(N, np.float32), csr_offsets=csr.offsets, csr_items=csr.items,
               x_uf=np.zeros((U, 1), np.float32), x_if=np.zeros((I, 1), np.float32), weights=synthetic.init_weights(U, I, F, seed=1492))
-    w0, g, rep, o, out, warm = _trained_then_one_epoch(oracle, sh, max_samples=50, warm_epochs=3, seed=1492)
-    print("config 3: draws per update gpu %.2f oracle %.2f (warm-up epochs %s); LL gpu/oracle - 1 = %+.4f; norms gpu/oracle %s"
-          % (rep["n_draws"][0] / N, out["nsamp"].sum() / N, np.round(warm["n_draws"] / N, 2), rep["log_likelihood"][0] / out["ll"][0] - 1.0,
-             [round(_norm_ratio(g[k], o[k]), 4) for k in ("v_u", "v_i", "w_i")]))
+    w0, g, rep, o, out, warm, (od, outd) = _trained_then_one_epoch(oracle, sh, max_samples=50, warm_epochs=3, seed=1492, damped=True)
+    for name, oo, oout in (("reference algorithm", o, out), ("oracle with the engine's step damping", od, outd)):
+        print("config 3 vs %s: draws per update gpu %.2f oracle %.2f (warm-up epochs %s); LL gpu/oracle - 1 = %+.4f; norms gpu/oracle %s"
+              % (name, rep["n_draws"][0] / N, oout["nsamp"].sum() / N, np.round(warm["n_draws"] / N, 2),
+                 rep["log_likelihood"][0] / oout["ll64"][0] - 1.0, [round(_norm_ratio(g[k], oo[k]), 4) for k in ("v_u", "v_i", "w_i")]))
     assert out["nsamp"].sum() > 1.5 * N                      # the multi-draw path is what is being compared
-    _assert_epoch_tracks_oracle(w0, g, rep, o, out, ("v_u", "v_i"), norm_tol=0.02, ll_tol=0.02, delta_corr=0.8, draws_tol=0.05)
-    # the item biases are the most order-sensitive table (the same 4 % the reference-backed quality test allows): measured +2.6 %
+    _assert_epoch_tracks_oracle(w0, g, rep, od, outd, ("v_u", "v_i", "w_i"), norm_tol=0.01, ll_tol=0.01, delta_corr=0.8, draws_tol=0.015)
+    _assert_epoch_tracks_oracle(w0, g, rep, o, out, ("v_u", "v_i"), norm_tol=0.02, ll_tol=0.0275, delta_corr=0.8, draws_tol=0.05)
     assert abs(_norm_ratio(g["w_i"], o["w_i"]) - 1.0) <= 0.04
 
 
@@ -173,6 +188,6 @@ def test_config5_subsample_tracks_sequential_oracle(oracle, c5_share):
     assert len(sub["interactions"]) == hi
     w0, g, rep, o, out, warm = _trained_then_one_epoch(oracle, sub, max_samples=50, warm_epochs=3, seed=77)
     print("config 5 sub-sample: draws per update gpu %.2f oracle %.2f; LL gpu/oracle - 1 = %+.4f; norms gpu/oracle %s"
-          % (rep["n_draws"][0] / hi, out["nsamp"].sum() / hi, rep["log_likelihood"][0] / out["ll"][0] - 1.0,
+          % (rep["n_draws"][0] / hi, out["nsamp"].sum() / hi, rep["log_likelihood"][0] / out["ll64"][0] - 1.0,
              [round(_norm_ratio(g[k], o[k]), 4) for k in ("v_u", "v_i", "w_i")]))
     _assert_epoch_tracks_oracle(w0, g, rep, o, out, ("v_u", "v_i", "w_i"), norm_tol=0.02, ll_tol=0.02, delta_corr=0.9, draws_tol=0.05)

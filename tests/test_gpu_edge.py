@@ -134,11 +134,11 @@ def test_epoch_parts_compose_to_the_whole_epoch():
     sw = np.ones(len(pairs), np.float32)
     w0 = synthetic.init_weights(200, 150, 16, seed=2)
     z_u, z_i = np.zeros((200, 1), np.float32), np.zeros((150, 1), np.float32)
-    # (debug_flags 1 | 8: one group, draws over the whole catalogue -- the negative-stripe schedule restarts with every launch,
-    # so with stripes the slices draw other, equally valid negatives than the whole epoch does: checked below)
-    whole = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=9)
+    # (one group, the default uniform sampler -- with the opt-in stripes the schedule restarts with every launch, so the slices
+    # draw other, equally valid negatives than the whole epoch does: checked below)
+    whole = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
     r0 = whole.run(epochs=1)
-    sliced = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=9)
+    sliced = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
     ll, draws = 0.0, 0
     for k in range(5):
         r = sliced.run(epochs=1, part=(k, 5))
@@ -150,7 +150,7 @@ def test_epoch_parts_compose_to_the_whole_epoch():
     assert draws == r0["n_draws"][0] == len(pairs) and ll == pytest.approx(r0["log_likelihood"][0], rel=1e-9)
     with pytest.raises(ValueError):
         sliced.run(epochs=1, part=(5, 5))
-    striped = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
+    striped = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1, negative_stripes=True)
     rs = [striped.run(epochs=1, part=(k, 5)) for k in range(5)]
     assert sum(int(r["n_draws"][0]) for r in rs) == len(pairs)
     assert sum(float(r["log_likelihood"][0]) for r in rs) == pytest.approx(r0["log_likelihood"][0], rel=0.02)

@@ -109,9 +109,9 @@ def main():
     # ---- config 2: two epochs from the initial weights ---------------------------------------------------------------------
     if "C2" in configs:
         w0p = save_weights(DATA["C2"]["weights"], "c2_init")
-        for variant, flags in (("stripes", 0), ("nostripes", 8)):
+        for variant, flags in (("stripes", 0), ("nostripes", 8)):     # (opt-in stripe sampler / the default uniform sampler)
             for r in range(a.runs):
-                s = session("C2", max_samples=1, seed=1492, debug_flags=flags)
+                s = session("C2", max_samples=1, seed=1492, negative_stripes=variant == "stripes")
                 with gpu():
                     rep = s.run(epochs=2)
                 g = s.weights_to_host()
@@ -127,7 +127,7 @@ def main():
                                geometry_order=geo, stripes=False)
                     if a.damped:
                         sys.path.insert(0, os.path.join(ROOT, "tools"))
-                        pos, user = step_scales(s, DATA["C2"], I, U)
+                        pos, user = s.step_scales()
                         sp = os.path.join(TMP, "c2_steps_%s.npz" % variant)
                         np.savez(sp, pos=pos, user=user)
                         submit(tag="C2:%s:damped_oracle" % variant, data="C2", weights=w0p, max_samples=1, epochs=[0, 1], seed=1492, lr=0.1,
@@ -148,8 +148,7 @@ def main():
             submit(tag="C3:%d:oracle" % r, data="C2", weights=wp, max_samples=50, epochs=[3], seed=1492, lr=0.1, geometry_order=s.geometry(),
                    stripes=False)
             if a.damped and r == 0:
-                cfg2 = synthetic.CONFIGS["C2"]
-                pos, user = step_scales(s, DATA["C2"], cfg2["n_items"], cfg2["n_users"])
+                pos, user = s.step_scales()
                 sp = os.path.join(TMP, "c3_steps.npz")
                 np.savez(sp, pos=pos, user=user)
                 submit(tag="C3:0:damped_oracle", data="C2", weights=wp, max_samples=50, epochs=[3], seed=1492, lr=0.1, geometry_order=s.geometry(),
@@ -212,24 +211,6 @@ def main():
             d, p = ora["C2:%s:damped_oracle" % v], ora["C2:%s:oracle" % v]
             print("C2 %s: damped / plain sequential oracle - 1: LL %s  |w_i| %+.2f%%" % (v, fmt(d["ll64"] / p["ll64"] - 1.0),
                                                                                       100.0 * (d["norms"]["w_i"] / p["norms"]["w_i"] - 1.0)))
-
-
-def step_scales(sess, d, I, U):
-    """the Hogwild step damping of the session's last run in the form the damped oracle takes (oracle.fit pos_step / user_step): the
-    per-item scale of the positive item's step decoded from the plan at the head of the engine's workspace (rfm_api.hip `carve`:
-    pos_scale [I] comes first; hot slots are encoded as scale + 2 (slot + 1)) and the per-user scale min(1, user_cap / degree) with
-    user_cap = M x segments / interactions in flight (rfm_api.hip "plan, part 3")."""
-    import torch
-    g = sess.geometry()
-    m = 128.0 if sess.hogwild_damping == 0 else sess.hogwild_damping
-    if m <= 0 or g.get("single_group"):
-        return np.ones(I, np.float32), np.ones(U, np.float32)
-    raw = sess._workspace[:4 * I].view(torch.float32).cpu().numpy().astype(np.float64)
-    slot = np.where(raw >= 2.0, np.floor(raw * 0.5), 0.0)
-    pos = (raw - 2.0 * slot).astype(np.float32)
-    user_cap = m * float(g["n_units"]) / float(g["working_groups"])
-    deg = np.maximum(np.diff(d["csr_offsets"]), 1)
-    return pos, np.minimum(1.0, user_cap / deg).astype(np.float32)
 
 
 if __name__ == "__main__":
