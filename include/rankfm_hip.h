@@ -175,7 +175,9 @@ typedef struct rfm_fit_report {
     int32_t stripe_rows;           /* items per negative stripe (include/rfm_rng.h), 0 = draws over the whole catalogue */
     int32_t stripe_window;         /* rows per group between stripe changes */
     int32_t segment_rows;          /* longest user segment of the plan (32; 16 when negative stripes are used), 0 = rows kernel */
-    int32_t reserved0;
+    int32_t table_producers;       /* features kernel: step-producer workgroups beside the table trainer, 0 = none */
+    int64_t table_steps;           /* features kernel: staged steps the table trainer applied over the call (it sees every
+                                      (epochs x N / table_steps)-th row of the stream) */
 } rfm_fit_report;
 
 int rfm_abi_version(void);

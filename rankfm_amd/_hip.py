@@ -77,13 +77,14 @@ class FitReport(C.Structure):
         ("plan_token", C.c_int64),
         ("workgroups", C.c_int32), ("groups_per_workgroup", C.c_int32), ("working_groups", C.c_int64),
         ("units_per_launch", C.c_int64), ("n_units", C.c_int64), ("stripe_rows", C.c_int32), ("stripe_window", C.c_int32),
-        ("segment_rows", C.c_int32), ("reserved0", C.c_int32),
+        ("segment_rows", C.c_int32), ("table_producers", C.c_int32), ("table_steps", C.c_int64),
     ]
 
     def geometry(self):
         """launch geometry as a dict (rankfm_amd.order mirrors the engine's negative draws from it)"""
         return {k: int(getattr(self, k)) for k in ("workgroups", "groups_per_workgroup", "working_groups", "units_per_launch",
-                                                   "n_units", "stripe_rows", "stripe_window", "launches_per_epoch", "segment_rows")}
+                                                   "n_units", "stripe_rows", "stripe_window", "launches_per_epoch", "segment_rows",
+                                                   "table_producers", "table_steps")}
 
 
 class ModelView(C.Structure):

@@ -566,7 +566,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     const bool feat_fast = feat && shape->group == 16 && cfg->max_samples == 1 && cfg->n_user_features <= 32 && cfg->n_item_features <= 32;
     std::vector<int> hot_order;
     if (damp && build_plan && use_segments && (!feat || feat_fast) && !(cfg->debug_flags & 4)) {
-        const double g0 = (double)(g_sm_count > 0 ? g_sm_count : 256) * 16.0 * (64 / shape->group);
+        // (interactions in flight: the full-chip geometry, or what the concurrency caps of the geometry below leave of it -- on a
+        // small problem a popular item is touched by a handful of concurrent updates at most, and accumulating it would only
+        // delay its updates: measured on the 3000 x 2000 feature-model fixture, |w_i| -4.6 % with, -0.8 % without)
+        const double g0 = std::min((double)(g_sm_count > 0 ? g_sm_count : 256) * 16.0 * (64 / shape->group),
+                                   (double)std::max<long long>(1, std::min<long long>(N / 128, (long long)std::min(cfg->n_users, cfg->n_items) / 3)));
         const double kHotMin = 16.0;
         for (int i = 0; i < cfg->n_items; ++i)
             if ((double)item_count[i] * g0 / (double)N >= kHotMin) hot_order.push_back(i);
@@ -904,7 +908,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->stripe_rows = stripe_rows;
         rep->stripe_window = stripe_window;
         rep->segment_rows = use_segments ? seg_rows : 0;
-        rep->reserved0 = 0;
+        rep->table_producers = n_producers;
+        rep->table_steps = (int64_t)h_err[2];
         rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40) | ((int64_t)seg_rows << 48)) : kRowsPlan);
     }
     return status;

@@ -1423,74 +1423,115 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
             // row walk below skips
             lds_float *rho_pow = stage + batch_floats;
             if (threadIdx.x <= (unsigned)gpb) rho_pow[threadIdx.x] = powf(1.0f - eta_f * reg_b, (float)threadIdx.x);
+            // The loop is software-pipelined: while batch q - 1 is being applied out of LDS, batch q is on its way from memory into
+            // registers and the ready flag of batch q + 1 is being polled, so that a batch costs the trainer its apply time and two
+            // barriers instead of three dependent memory round trips (flag, data, publication).
+            constexpr int kPre = 16;                                  // dwords of a batch a thread keeps in flight
+            float pre[kPre];
+            unsigned applied = 0;
+            bool staged = false;                                      // LDS holds a batch that has not been applied yet
+            unsigned flag_next = 0;                                   // (thread 0) the ready counter of the next batch, loaded ahead
+            auto slot_of = [&](unsigned q, int &p, unsigned &par, unsigned &m) {
+                p = NP > 0 ? (int)(q % (unsigned)NP) : 0;
+                const unsigned n_p = NP > 0 ? q / (unsigned)NP : q;
+                par = n_p & 1u; m = n_p >> 1;
+            };
+            if (threadIdx.x == 0 && NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             for (unsigned q = 0;; ++q) {
-                const int p = NP > 0 ? (int)(q % (unsigned)NP) : 0;
-                const unsigned n_p = NP > 0 ? q / (unsigned)NP : q, par = n_p & 1u, m = n_p >> 1;
+                int p;
+                unsigned par, m;
+                slot_of(q, p, par, m);
                 if (threadIdx.x == 0) {
                     int stop = 0;
-                    for (unsigned spin = 0;; ++spin) {
-                        // (the row loops' end is checked FIRST: the producers stay ahead of the trainer, so a batch is always ready)
-                        if (flag_load(flags + kFeatDone) >= (unsigned)n_regular) { stop = 1; break; }
-                        if (NP > 0 && flag_load(flags + kFeatReady + 2 * p + par) >= m + 1u) break;
+                    // (the row loops' end is looked at every 16th batch and whenever the trainer has to wait: the producers stay ahead of
+                    // it, so without the periodic look it would never stop)
+                    if ((q & 15u) == 0u && __hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) stop = 1;
+                    for (unsigned spin = 0; !stop && (NP == 0 || flag_next < m + 1u); ++spin) {
+                        if (__hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) { stop = 1; break; }
                         if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }      // (never observed: a hang guard)
-                        __builtin_amdgcn_s_sleep(8);
+                        __builtin_amdgcn_s_sleep(4);
+                        if (NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady + 2 * p + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       // the batch's data is read after its flag
                     s_stop = stop;
                 }
                 __syncthreads();
                 if (s_stop) break;
+                // batch q: on its way into registers (the part beyond kPre dwords per thread goes straight to LDS below)
                 const float *src = a.feat_ring + (size_t)(2 * p + par) * batch_floats;
-                for (size_t k = threadIdx.x; k < batch_floats; k += blockDim.x)
-                    stage[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __syncthreads();
-                if (threadIdx.x == 0) flag_store(flags + kFeatConsumed + 2 * p + par, m + 1u);
-                // Apply the staged steps.  Within one interaction the table rows do not read each other, so the reference's
-                // sequential update of the tables over the batch (rankfm/_rankfm.pyx:283-286, 313-326) is, for each table ROW, a walk
-                // over the interactions that touch it -- all rows at once, one row group per row with the row in registers, plain
-                // read and write.  The interactions that touch the row are found by the group's lanes together (one ballot per G
-                // staged steps); the row of v_if for tag q also carries w_if[q] (lane 0).
-                for (int r = gid; r < a.n_uf + a.n_if; r += gpb) {
-                    const bool uf = r < a.n_uf;
-                    if (uf ? !a.has_uf : !a.has_if) continue;
-                    lds_float *row = lds + (size_t)r * F;                                  // v_uf rows, then v_if rows
-                    const int xoff = 1 + 2 * F + r, voff = uf ? 1 + F : 1;                   // coefficient; vector: v_i - v_j | v_u
-                    float tr[KPL];
 #pragma unroll
-                    for (int k = 0; k < KPL; ++k) tr[k] = (sub + G * k < F) ? row[sub + G * k] : 0.0f;
-                    float wq = uf ? 0.0f : lds[n_uf_f + n_if_f + (r - a.n_uf)];
-                    int last = -1;                                                          // last staged step applied to w_if[q]
-                    for (int c0 = 0; c0 < gpb; c0 += G) {
-                        const int mine = c0 + sub;
-                        const bool on = mine < gpb && stage[(size_t)mine * n_slot + xoff] != 0.0f;
-                        unsigned long long bits;
-                        if constexpr (G == 64) bits = __ballot(on);
-                        else bits = (unsigned long long)group_ballot<G>(on);
-                        while (bits) {
-                            const int b = __ffsll((long long)bits) - 1;
-                            bits &= bits - 1;
-                            const int s2 = c0 + b;
-                            const lds_float *st = stage + (size_t)s2 * n_slot;
-                            const float c = st[0] * st[xoff];
-#pragma unroll
-                            for (int k = 0; k < KPL; ++k)
-                                if (sub + G * k < F) tr[k] += eta_f * (c * st[voff + sub + G * k] - reg_b * tr[k]);
-                            if (!uf) {
-                                wq = wq * rho_pow[s2 - last - 1];                          // the untouched interactions in between
-                                wq += eta_f * (c - reg_b * wq);
-                                last = s2;
+                for (int j = 0; j < kPre; ++j) {
+                    const size_t k = threadIdx.x + (size_t)j * blockDim.x;
+                    pre[j] = k < batch_floats ? __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0f;
+                }
+                if (threadIdx.x == 0 && NP > 0) {                     // ... and the flag of batch q + 1
+                    int p1;
+                    unsigned par1, m1;
+                    slot_of(q + 1, p1, par1, m1);
+                    flag_next = __hip_atomic_load(flags + kFeatReady + 2 * p1 + par1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (staged) {
+                    // Apply the staged steps.  Within one interaction the table rows do not read each other, so the reference's
+                    // sequential update of the tables over the batch (rankfm/_rankfm.pyx:283-286, 313-326) is, for each table ROW, a walk
+                    // over the interactions that touch it -- all rows at once, one row group per row with the row in registers, plain
+                    // read and write.  The interactions that touch the row are found by the group's lanes together (one ballot per G
+                    // staged steps); the row of v_if for tag q also carries w_if[q] (lane 0).
+                    for (int r = gid; r < a.n_uf + a.n_if; r += gpb) {
+                        const bool uf = r < a.n_uf;
+                        if (uf ? !a.has_uf : !a.has_if) continue;
+                        lds_float *row = lds + (size_t)r * F;                                  // v_uf rows, then v_if rows
+                        const int xoff = 1 + 2 * F + r, voff = uf ? 1 + F : 1;                   // coefficient; vector: v_i - v_j | v_u
+                        float tr[KPL];
+    #pragma unroll
+                        for (int k = 0; k < KPL; ++k) tr[k] = (sub + G * k < F) ? row[sub + G * k] : 0.0f;
+                        float wq = uf ? 0.0f : lds[n_uf_f + n_if_f + (r - a.n_uf)];
+                        int last = -1;                                                          // last staged step applied to w_if[q]
+                        for (int c0 = 0; c0 < gpb; c0 += G) {
+                            const int mine = c0 + sub;
+                            const bool on = mine < gpb && stage[(size_t)mine * n_slot + xoff] != 0.0f;
+                            unsigned long long bits;
+                            if constexpr (G == 64) bits = __ballot(on);
+                            else bits = (unsigned long long)group_ballot<G>(on);
+                            while (bits) {
+                                const int b = __ffsll((long long)bits) - 1;
+                                bits &= bits - 1;
+                                const int s2 = c0 + b;
+                                const lds_float *st = stage + (size_t)s2 * n_slot;
+                                const float c = st[0] * st[xoff];
+    #pragma unroll
+                                for (int k = 0; k < KPL; ++k)
+                                    if (sub + G * k < F) tr[k] += eta_f * (c * st[voff + sub + G * k] - reg_b * tr[k]);
+                                if (!uf) {
+                                    wq = wq * rho_pow[s2 - last - 1];                          // the untouched interactions in between
+                                    wq += eta_f * (c - reg_b * wq);
+                                    last = s2;
+                                }
                             }
                         }
+    #pragma unroll
+                        for (int k = 0; k < KPL; ++k)
+                            if (sub + G * k < F) row[sub + G * k] = tr[k];
+                        if (!uf && sub == 0) lds[n_uf_f + n_if_f + (r - a.n_uf)] = wq * rho_pow[gpb - 1 - last];
                     }
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        if (sub + G * k < F) row[sub + G * k] = tr[k];
-                    if (!uf && sub == 0) lds[n_uf_f + n_if_f + (r - a.n_uf)] = wq * rho_pow[gpb - 1 - last];
+                    __syncthreads();
+                    // publish the master copy (write-through to memory)
+                    for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
+                        __hip_atomic_store(table_ptr(k), lds_tables[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    applied += (unsigned)gpb;
                 }
+                // batch q into the staging area (everybody has finished reading batch q - 1: the barrier above / the first round)
+#pragma unroll
+                for (int j = 0; j < kPre; ++j) {
+                    const size_t k = threadIdx.x + (size_t)j * blockDim.x;
+                    if (k < batch_floats) stage[k] = pre[j];
+                }
+                for (size_t k = threadIdx.x + (size_t)kPre * blockDim.x; k < batch_floats; k += blockDim.x)
+                    stage[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                staged = true;
                 __syncthreads();
-                // publish the master copy (write-through to memory)
-                for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
-                    __hip_atomic_store(table_ptr(k), lds_tables[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (threadIdx.x == 0) flag_store(flags + kFeatConsumed + 2 * p + par, m + 1u);      // (the loads have returned: the slot is free)
             }
+            if (threadIdx.x == 0 && applied) atomicAdd(a.error_flags + 2, applied);      // staged steps applied (rfm_fit_report.table_steps)
             // the launch is over: release the producers, wait until they have left, and leave the flags zero for the next launch
             if (threadIdx.x == 0) {
                 flag_store(flags + kFeatStop, 1u);

@@ -54,10 +54,13 @@ def test_feature_model_matches_the_reference():
         assert len(train) == int(ref[seed, cols.index("n_train")])
         uf = pd.DataFrame(np.column_stack([np.arange(len(d["user_tags"])), d["user_tags"]]))
         itf = pd.DataFrame(np.column_stack([np.arange(len(d["item_tags"])), d["item_tags"]]))
-        m = RankFM(factors=20, loss="bpr", learning_rate=0.03)
-        np.random.seed(seed)
-        m.fit(train, user_features=uf, item_features=itf, epochs=5)
-        got.append([evaluation.hit_rate(m, test, k=10)] + [np.linalg.norm(getattr(m, k)) for k in ("v_u", "v_i", "w_i", "v_uf", "v_if", "w_if")])
+        # three engine runs per data seed: on 3000 test users ONE Hogwild run's hit rate moves by +-2 points from run to run (measured:
+        # tools/feature_quality.py), which would make a five-run mean a coin toss against a 1.5-point bar
+        for run in range(3):
+            m = RankFM(factors=20, loss="bpr", learning_rate=0.03)
+            np.random.seed(seed)
+            m.fit(train, user_features=uf, item_features=itf, epochs=5)
+            got.append([evaluation.hit_rate(m, test, k=10)] + [np.linalg.norm(getattr(m, k)) for k in ("v_u", "v_i", "w_i", "v_uf", "v_if", "w_if")])
     got, want = np.mean(got, axis=0), ref[:, :7].mean(axis=0)
     print("feature model: got", np.round(got, 4), "reference", np.round(want, 4))
     assert abs(got[0] - want[0]) <= 0.015, ("hit_rate@10", got[0], want[0])
