@@ -178,6 +178,9 @@ typedef struct rfm_fit_report {
     int32_t table_producers;       /* features kernel: step-producer workgroups beside the table trainer, 0 = none */
     int64_t table_steps;           /* features kernel: staged steps the table trainer applied over the call (it sees every
                                       (epochs x N / table_steps)-th row of the stream) */
+    int64_t feat_diag[8];          /* features kernel, microseconds over the call: the trainer waited for a batch | ran in all |
+                                      the producers waited for a free slot (summed) | ran in all (summed) | the trainer's apply |
+                                      publication | batch into LDS | slot release */
 } rfm_fit_report;
 
 int rfm_abi_version(void);

@@ -77,11 +77,14 @@ class FitReport(C.Structure):
         ("plan_token", C.c_int64),
         ("workgroups", C.c_int32), ("groups_per_workgroup", C.c_int32), ("working_groups", C.c_int64),
         ("units_per_launch", C.c_int64), ("n_units", C.c_int64), ("stripe_rows", C.c_int32), ("stripe_window", C.c_int32),
-        ("segment_rows", C.c_int32), ("table_producers", C.c_int32), ("table_steps", C.c_int64),
+        ("segment_rows", C.c_int32), ("table_producers", C.c_int32), ("table_steps", C.c_int64), ("feat_diag", C.c_int64 * 8),
     ]
 
     def geometry(self):
         """launch geometry as a dict (rankfm_amd.order mirrors the engine's negative draws from it)"""
+        return dict(self._geometry(), feat_diag=[int(x) for x in self.feat_diag])
+
+    def _geometry(self):
         return {k: int(getattr(self, k)) for k in ("workgroups", "groups_per_workgroup", "working_groups", "units_per_launch",
                                                    "n_units", "stripe_rows", "stripe_window", "launches_per_epoch", "segment_rows",
                                                    "table_producers", "table_steps")}

@@ -234,7 +234,7 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.draws = (unsigned long long *)(p + o);     o += align_up(sizeof(unsigned long long) * epochs);
     w.sumsq = (double *)(p + o);                 o += align_up(sizeof(double) * 6 * epochs);
     w.nonfinite = (unsigned int *)(p + o);       o += align_up(sizeof(unsigned int) * epochs);
-    w.error_flags = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int) * 4);
+    w.error_flags = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int) * 16);
     w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
     w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
     w.feat_flags = (unsigned int *)(p + o);      o += align_up(sizeof(unsigned int) * kFeatFlagWords);
@@ -605,8 +605,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     int feat_waves = 16;
     if (cfg->tune_feature_waves > 0) feat_waves = std::max(2, std::min(16, cfg->tune_feature_waves));
     // (the table trainer also stages one step per row group: 1 + 2F + P + Q floats each; wide tables take smaller workgroups)
-    while (feat_waves > 2 && sizeof(float) * (feat_table_floats(cfg) + (size_t)feat_waves * (64 / shape->group) *
-                                              (2 + 2 * (size_t)cfg->n_factors + cfg->n_user_features + cfg->n_item_features) + 1) > kLdsBytes)
+    while (feat_waves > 2 && sizeof(float) * (feat_table_floats(cfg) + 8 + (size_t)feat_waves * (64 / shape->group) *
+                                              (5 + 2 * (size_t)shape->group * shape->kpl + cfg->n_user_features + cfg->n_item_features)) > kLdsBytes)
         feat_waves /= 2;
     const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : ((use_hot || use_stripes) ? 16 : 4));   // see sgd_segments_kernel
     // stripe geometry: as many rows as the LDS left by the hot-row accumulators holds (at most 256: more rows mean longer
@@ -654,12 +654,12 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         if (grid < 1 || single_group) grid = 1;
         // features kernel: workgroup 0 is the table trainer and workgroups 1 .. n_producers stage the steps it applies
         // (sgd_features_kernel) -- resident workgroups like the others, not extra ones (a workgroup that had to wait for a free
-        // CU would run its share after everybody else).  A producer delivers ~4 staged steps per microsecond, a row loop
-        // workgroup trains ~5 rows in that time: one producer per ~16 row-loop workgroups lets the trainer see every ~20th row
-        // of the stream until its own apply rate (~30 steps per microsecond) is the limit.
+        // CU would run its share after everybody else).  Measured on config 4's share (rfm_fit_report.feat_diag, profiles/r03_notes.md):
+        // a producer stages a batch of 64 steps in ~33 us, the trainer applies one in ~12 us (its apply walk is bound by the LDS
+        // pipe of its CU): three or four producers keep it busy; with twelve they waited 77 % of the time.
         if (use_segments && feat && !single_group && !feat_frozen) {
             const int64_t room = std::max<int64_t>(cap, 3);
-            n_producers = (int)std::max<int64_t>(1, std::min<int64_t>(12, ((int64_t)grid + 15) / 16));
+            n_producers = (int)std::max<int64_t>(1, std::min<int64_t>(4, ((int64_t)grid + 3) / 4));
             if (cfg->tune_table_producers > 0) n_producers = std::min(kFeatMaxProducers, cfg->tune_table_producers);
             if (grid + 1 + n_producers > room) grid = (int)std::max<int64_t>(1, room - 1 - n_producers);
             grid += 1 + n_producers;
@@ -855,9 +855,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     std::vector<double> h_ll(E), h_sumsq((size_t)6 * E);
     std::vector<unsigned long long> h_draws(E);
     std::vector<unsigned int> h_nonfinite(E);
-    unsigned int h_err[4] = {0, 0, 0, 0};
+    unsigned int h_err[16] = {0};
     // ll | draws | sumsq | nonfinite | error_flags are laid out back to back: one copy, one synchronisation
-    const size_t res_bytes = (size_t)((const char *)(ws.error_flags + 4) - (const char *)ws.ll);
+    const size_t res_bytes = (size_t)((const char *)(ws.error_flags + 16) - (const char *)ws.ll);
     std::vector<char> h_res(res_bytes);
     RFM_HIP(hipMemcpyAsync(h_res.data(), ws.ll, res_bytes, hipMemcpyDeviceToHost, stream));
     RFM_HIP(hipStreamSynchronize(stream));
@@ -910,6 +910,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->segment_rows = use_segments ? seg_rows : 0;
         rep->table_producers = n_producers;
         rep->table_steps = (int64_t)h_err[2];
+        for (int k = 0; k < 8; ++k) rep->feat_diag[k] = (int64_t)h_err[4 + k];
         rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40) | ((int64_t)seg_rows << 48)) : kRowsPlan);
     }
     return status;

@@ -1347,8 +1347,14 @@ constexpr int kFeatDone = kFeatStop + 2;                       // regular workgr
 constexpr int kFeatFlagWords = kFeatStop + 4;
 constexpr unsigned kFeatSpinLimit = 1u << 23;                  // polls (~0.5 us each) before a waiting workgroup gives up: seconds
 
-__device__ __forceinline__ unsigned flag_load(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void flag_store(unsigned int *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// (The trainer and the producers are non-inlined functions that receive SgdArgs by value: the compiler no longer knows that its
+// pointers are global memory, and a FLAT load counts against the LDS counter as well -- every LDS wait of the trainer's apply loop
+// waited for the batch in flight (measured: 17 us per batch instead of 6).  Their hot pointers are therefore cast to the global
+// address space explicitly.)
+typedef __attribute__((address_space(1))) float g_float;
+typedef __attribute__((address_space(1))) unsigned int g_uint;
+__device__ __forceinline__ unsigned flag_load(const g_uint *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void flag_store(g_uint *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // The pipelined row loop keeps its LDS copy of v_uf / v_if LANE-MAJOR: the KPL factor dwords lane s of a row group owns (s, s + 16,
 // ...) are consecutive, so a table row costs the lane one 16-byte LDS read instead of KPL 4-byte ones.  Row stride 16 * KPL.
@@ -1393,206 +1399,382 @@ __device__ __forceinline__ void project_dense(float xr0, float xr1, int n, const
 #undef RFM_PSTEP
 }
 
-template <int G, int KPL, bool FRESH, bool WARPB>
-__global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    const int sub = lane % G;
-    const int F = a.n_factors;
-    extern __shared__ __attribute__((aligned(16))) float lds_tables[];
-    lds_float *lds = (lds_float *)lds_tables;
-    const int n_uf_f = a.n_uf * F, n_if_f = a.n_if * F, n_tab = n_uf_f + n_if_f + a.n_if;
-    auto table_ptr = [&](int k) { return k < n_uf_f ? a.v_uf + k : (k < n_uf_f + n_if_f ? a.v_if + (k - n_uf_f) : a.w_if + (k - n_uf_f - n_if_f)); };
-    const int NP = a.single_group ? 0 : a.n_producers;               // (one group alone: no trainer, no producers)
-    const bool trains = !a.single_group && !a.feat_frozen;
-    unsigned int *flags = a.feat_flags;
-    const int gid = threadIdx.x / G, gpb = blockDim.x / G;
-    const int n_slot = 1 + 2 * F + a.n_uf + a.n_if;                  // staged step of one interaction (RowStep::stage)
-    const size_t batch_floats = (size_t)gpb * n_slot;
-    const int n_regular = (int)gridDim.x - (trains ? 1 + NP : 0);
+// locals every role of the features kernel derives from the launch (trainer, producers, row loops)
+#define RFM_FEAT_LOCALS                                                                                                                   \
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;                                                \
+    const int sub = lane % G;                                                                                                             \
+    const int F = a.n_factors;                                                                                                            \
+    lds_float *lds_tables = lds;                                                                                                          \
+    const int n_uf_f = a.n_uf * F, n_if_f = a.n_if * F, n_tab = n_uf_f + n_if_f + a.n_if;                                                  \
+    auto table_ptr = [&](int k) { return (g_float *)(k < n_uf_f ? a.v_uf + k : (k < n_uf_f + n_if_f ? a.v_if + (k - n_uf_f) : a.w_if + (k - n_uf_f - n_if_f))); }; \
+    const int NP = a.single_group ? 0 : a.n_producers;               /* (one group alone: no trainer, no producers) */                    \
+    const bool trains = !a.single_group && !a.feat_frozen;                                                                                \
+    g_uint *flags = (g_uint *)a.feat_flags;                                                                                               \
+    const int gid = threadIdx.x / G, gpb = blockDim.x / G;                                                                                \
+    const int n_slot = 1 + 2 * F + a.n_uf + a.n_if;                  /* staged step of one interaction (RowStep::stage) */                \
+    const size_t batch_floats = (size_t)gpb * n_slot;                                                                                     \
+    const int n_regular = (int)gridDim.x - (trains ? 1 + NP : 0);                                                                         \
+    (void)lane; (void)wave; (void)n_waves; (void)sub; (void)gid; (void)flags; (void)batch_floats; (void)n_regular; (void)lds_tables; (void)table_ptr;
 
-    if (trains && blockIdx.x <= (unsigned)NP) {
-        // natural layout of the tables: [P, F] | [Q, F] | [Q]
-        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
-        lds_float *stage = lds + n_tab;
-        __shared__ int s_stop;
-        __syncthreads();
-        if (blockIdx.x == 0) {
-            // ---- the table trainer ------------------------------------------------------------------------------------------
-            const float eta_f = a.eta, reg_b = a.reg_b;
-            // rho^n, n = 0 .. gpb: w_if shrinks on EVERY interaction (:283-286), also those whose tag difference is zero, which the
-            // row walk below skips
-            lds_float *rho_pow = stage + batch_floats;
-            if (threadIdx.x <= (unsigned)gpb) rho_pow[threadIdx.x] = powf(1.0f - eta_f * reg_b, (float)threadIdx.x);
-            // The loop is software-pipelined: while batch q - 1 is being applied out of LDS, batch q is on its way from memory into
-            // registers and the ready flag of batch q + 1 is being polled, so that a batch costs the trainer its apply time and two
-            // barriers instead of three dependent memory round trips (flag, data, publication).
-            constexpr int kPre = 16;                                  // dwords of a batch a thread keeps in flight
-            float pre[kPre];
-            unsigned applied = 0;
-            bool staged = false;                                      // LDS holds a batch that has not been applied yet
-            unsigned flag_next = 0;                                   // (thread 0) the ready counter of the next batch, loaded ahead
-            auto slot_of = [&](unsigned q, int &p, unsigned &par, unsigned &m) {
-                p = NP > 0 ? (int)(q % (unsigned)NP) : 0;
-                const unsigned n_p = NP > 0 ? q / (unsigned)NP : q;
-                par = n_p & 1u; m = n_p >> 1;
-            };
-            if (threadIdx.x == 0 && NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            for (unsigned q = 0;; ++q) {
-                int p;
-                unsigned par, m;
-                slot_of(q, p, par, m);
-                if (threadIdx.x == 0) {
-                    int stop = 0;
-                    // (the row loops' end is looked at every 16th batch and whenever the trainer has to wait: the producers stay ahead of
-                    // it, so without the periodic look it would never stop)
-                    if ((q & 15u) == 0u && __hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) stop = 1;
-                    for (unsigned spin = 0; !stop && (NP == 0 || flag_next < m + 1u); ++spin) {
-                        if (__hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) { stop = 1; break; }
-                        if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }      // (never observed: a hang guard)
-                        __builtin_amdgcn_s_sleep(4);
-                        if (NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady + 2 * p + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       // the batch's data is read after its flag
-                    s_stop = stop;
-                }
-                __syncthreads();
-                if (s_stop) break;
-                // batch q: on its way into registers (the part beyond kPre dwords per thread goes straight to LDS below)
-                const float *src = a.feat_ring + (size_t)(2 * p + par) * batch_floats;
+// The roles of the features kernel other than the pipelined row loop are separate (non-inlined) functions: each gets a register
+// allocation of its own, so that the trainer's batch in flight or the generic step's feature vectors do not cost the row loop spills.
+template <int G, int KPL>
+__device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, lds_float *lds, lds_int *s_stop_p) {
+    RFM_FEAT_LOCALS
+    // natural layout of the tables: [P, F] | [Q, F] | [Q]
+    for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
+    // The staging area holds a batch in the TRAINER'S layout: per staged step [updated v_u | updated v_i - v_j | g * d_outer | x_uf[u] |
+    // x_if[i] - x_if[j]], the two vectors lane-major and padded to the group width (lane s of a row group reads its KPL dwords with
+    // one 16-byte LDS read, no per-dword bounds predicate), slots padded to a multiple of four floats.
+    constexpr int FS = G * KPL;
+    const int NSL = (2 * FS + 1 + a.n_uf + a.n_if + 3) & ~3;
+    lds_float *stage = lds + ((n_tab + 3) & ~3);
+    __syncthreads();
+    // ---- the table trainer ------------------------------------------------------------------------------------------
+    const float eta_f = a.eta, reg_b = a.reg_b;
+    // rho^n, n = 0 .. gpb: w_if shrinks on EVERY interaction (:283-286), also those whose tag difference is zero, which the
+    // row walk below skips
+    lds_float *rho_pow = stage + (size_t)gpb * NSL;
+    if (threadIdx.x <= (unsigned)gpb) rho_pow[threadIdx.x] = powf(1.0f - eta_f * reg_b, (float)threadIdx.x);
+    for (size_t k = threadIdx.x; k < (size_t)gpb * NSL; k += blockDim.x) stage[k] = 0.0f;     // (the padding is read, never written)
+    // The loop is software-pipelined: while batch q - 1 is being applied out of LDS, batch q is on its way from memory into
+    // registers and the ready flag of batch q + 1 is being polled, so that a batch costs the trainer its apply time and two
+    // barriers instead of three dependent memory round trips (flag, data, publication).
+    constexpr int kPre = 14;                                  // dwords of a batch a thread keeps in flight
+    float pre[kPre];
+    const unsigned n_batch = (unsigned)batch_floats, n_threads = blockDim.x;
+    // where dword threadIdx.x + j * blockDim.x of a batch (the producers' layout: RowStep::stage, [g d_outer | v_u | v_i - v_j | x_uf |
+    // x_if diff] per step) goes in the staging area; the same for every batch, so computed once
+    auto stage_index = [&](size_t k) {
+        const int s2 = (int)(k / (size_t)n_slot), off = (int)(k - (size_t)s2 * n_slot);
+        int dst;
+        if (off == 0) dst = 2 * FS;
+        else if (off < 1 + 2 * F) {
+            const int v = off - 1 < F ? 0 : 1, f = off - 1 - v * F;
+            dst = v * FS + (f % G) * KPL + f / G;
+        } else dst = 2 * FS + 1 + (off - 1 - 2 * F);
+        return s2 * NSL + dst;
+    };
+    // (two 16-bit staging indexes per register; 0xFFFF = none.  Register pressure matters here: a spilled value reloaded between two
+    // of the batch's loads waits for every load issued before it -- the system-scope loads return in order)
+    unsigned pre_dst[(kPre + 1) / 2];
 #pragma unroll
-                for (int j = 0; j < kPre; ++j) {
-                    const size_t k = threadIdx.x + (size_t)j * blockDim.x;
-                    pre[j] = k < batch_floats ? __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0f;
-                }
-                if (threadIdx.x == 0 && NP > 0) {                     // ... and the flag of batch q + 1
-                    int p1;
-                    unsigned par1, m1;
-                    slot_of(q + 1, p1, par1, m1);
-                    flag_next = __hip_atomic_load(flags + kFeatReady + 2 * p1 + par1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                if (staged) {
-                    // Apply the staged steps.  Within one interaction the table rows do not read each other, so the reference's
-                    // sequential update of the tables over the batch (rankfm/_rankfm.pyx:283-286, 313-326) is, for each table ROW, a walk
-                    // over the interactions that touch it -- all rows at once, one row group per row with the row in registers, plain
-                    // read and write.  The interactions that touch the row are found by the group's lanes together (one ballot per G
-                    // staged steps); the row of v_if for tag q also carries w_if[q] (lane 0).
-                    for (int r = gid; r < a.n_uf + a.n_if; r += gpb) {
-                        const bool uf = r < a.n_uf;
-                        if (uf ? !a.has_uf : !a.has_if) continue;
-                        lds_float *row = lds + (size_t)r * F;                                  // v_uf rows, then v_if rows
-                        const int xoff = 1 + 2 * F + r, voff = uf ? 1 + F : 1;                   // coefficient; vector: v_i - v_j | v_u
-                        float tr[KPL];
-    #pragma unroll
-                        for (int k = 0; k < KPL; ++k) tr[k] = (sub + G * k < F) ? row[sub + G * k] : 0.0f;
-                        float wq = uf ? 0.0f : lds[n_uf_f + n_if_f + (r - a.n_uf)];
-                        int last = -1;                                                          // last staged step applied to w_if[q]
-                        for (int c0 = 0; c0 < gpb; c0 += G) {
-                            const int mine = c0 + sub;
-                            const bool on = mine < gpb && stage[(size_t)mine * n_slot + xoff] != 0.0f;
-                            unsigned long long bits;
-                            if constexpr (G == 64) bits = __ballot(on);
-                            else bits = (unsigned long long)group_ballot<G>(on);
-                            while (bits) {
-                                const int b = __ffsll((long long)bits) - 1;
-                                bits &= bits - 1;
-                                const int s2 = c0 + b;
-                                const lds_float *st = stage + (size_t)s2 * n_slot;
-                                const float c = st[0] * st[xoff];
-    #pragma unroll
-                                for (int k = 0; k < KPL; ++k)
-                                    if (sub + G * k < F) tr[k] += eta_f * (c * st[voff + sub + G * k] - reg_b * tr[k]);
-                                if (!uf) {
-                                    wq = wq * rho_pow[s2 - last - 1];                          // the untouched interactions in between
-                                    wq += eta_f * (c - reg_b * wq);
-                                    last = s2;
-                                }
-                            }
-                        }
-    #pragma unroll
-                        for (int k = 0; k < KPL; ++k)
-                            if (sub + G * k < F) row[sub + G * k] = tr[k];
-                        if (!uf && sub == 0) lds[n_uf_f + n_if_f + (r - a.n_uf)] = wq * rho_pow[gpb - 1 - last];
-                    }
-                    __syncthreads();
-                    // publish the master copy (write-through to memory)
-                    for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
-                        __hip_atomic_store(table_ptr(k), lds_tables[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    applied += (unsigned)gpb;
-                }
-                // batch q into the staging area (everybody has finished reading batch q - 1: the barrier above / the first round)
-#pragma unroll
-                for (int j = 0; j < kPre; ++j) {
-                    const size_t k = threadIdx.x + (size_t)j * blockDim.x;
-                    if (k < batch_floats) stage[k] = pre[j];
-                }
-                for (size_t k = threadIdx.x + (size_t)kPre * blockDim.x; k < batch_floats; k += blockDim.x)
-                    stage[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                staged = true;
-                __syncthreads();
-                if (threadIdx.x == 0) flag_store(flags + kFeatConsumed + 2 * p + par, m + 1u);      // (the loads have returned: the slot is free)
+    for (int j = 0; j < kPre; j += 2) {
+        const unsigned k0 = threadIdx.x + (unsigned)j * n_threads, k1 = k0 + n_threads;
+        const unsigned d0 = k0 < n_batch ? (unsigned)stage_index(k0) : 0xFFFFu, d1 = (j + 1 < kPre && k1 < n_batch) ? (unsigned)stage_index(k1) : 0xFFFFu;
+        pre_dst[j / 2] = d0 | (d1 << 16);
+    }
+    const bool prefetch_ok = (size_t)gpb * NSL < 0xFFFFu;    // (else every dword of a batch takes the direct path below)
+    unsigned applied = 0;
+    bool staged = false;                                      // LDS holds a batch that has not been applied yet
+    unsigned flag_next = 0;                                   // (thread 0) the ready counter of the next batch, loaded ahead
+    auto slot_of = [&](unsigned q, int &p, unsigned &par, unsigned &m) {
+        p = NP > 0 ? (int)(q % (unsigned)NP) : 0;
+        const unsigned n_p = NP > 0 ? q / (unsigned)NP : q;
+        par = n_p & 1u; m = n_p >> 1;
+    };
+    if (threadIdx.x == 0 && NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (diagnostics, rfm_fit_report.feat_diag: time this workgroup waited for a batch / ran in all, in 100 MHz ticks)
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long t_wait = 0, t_seg[4] = {0, 0, 0, 0};      // (apply | publish | batch into LDS | slot release)
+    for (unsigned q = 0;; ++q) {
+        int p;
+        unsigned par, m;
+        slot_of(q, p, par, m);
+        if (threadIdx.x == 0) {
+            int stop = 0;
+            // (the row loops' end is looked at every 16th batch and whenever the trainer has to wait: the producers stay ahead of
+            // it, so without the periodic look it would never stop)
+            if ((q & 15u) == 0u && __hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) stop = 1;
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned spin = 0; !stop && (NP == 0 || flag_next < m + 1u); ++spin) {
+                if (__hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) { stop = 1; break; }
+                if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }      // (never observed: a hang guard)
+                __builtin_amdgcn_s_sleep(4);
+                if (NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady + 2 * p + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            if (threadIdx.x == 0 && applied) atomicAdd(a.error_flags + 2, applied);      // staged steps applied (rfm_fit_report.table_steps)
-            // the launch is over: release the producers, wait until they have left, and leave the flags zero for the next launch
-            if (threadIdx.x == 0) {
-                flag_store(flags + kFeatStop, 1u);
-                for (unsigned spin = 0; flag_load(flags + kFeatExited) < (unsigned)NP && spin <= kFeatSpinLimit; ++spin) __builtin_amdgcn_s_sleep(8);
-                for (int k = 0; k < kFeatFlagWords; ++k) flag_store(flags + k, 0u);
-            }
-            return;
+            t_wait += wall_clock64() - t0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       // the batch's data is read after its flag
+            *s_stop_p = stop;
         }
-        // ---- a step producer ----------------------------------------------------------------------------------------------------
-        typedef RowStep<G, KPL, false, true, true, true, true, false, WARPB, false, 1> Train;
-        Train step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
-        const int p = (int)blockIdx.x - 1;
-        double ll_unused = 0.0;
-        unsigned draws_unused = 0;
-        for (unsigned n = 0;; ++n) {
-            const unsigned par = n & 1u, m = n >> 1;
-            if (threadIdx.x == 0) {
-                int stop = 0;
-                for (unsigned spin = 0;; ++spin) {           // the slot must have been emptied m times
-                    if (flag_load(flags + kFeatStop)) { stop = 1; break; }
-                    if (flag_load(flags + kFeatConsumed + 2 * p + par) >= m) break;
-                    if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }
-                    __builtin_amdgcn_s_sleep(8);
+        __syncthreads();
+        if (*s_stop_p) break;
+        const unsigned long long tA = wall_clock64();
+        // batch q: on its way into registers (the part beyond kPre dwords per thread goes straight to LDS below)
+        const g_float *src = (const g_float *)a.feat_ring + (size_t)(2 * p + par) * batch_floats;
+        {
+            const g_float *pp = src + threadIdx.x;
+            unsigned k = threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) {
+                pre[j] = (prefetch_ok && k < n_batch) ? __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0f;
+                pp += n_threads;
+                k += n_threads;
+            }
+        }
+        if (threadIdx.x == 0 && NP > 0) {                     // ... and the flag of batch q + 1
+            int p1;
+            unsigned par1, m1;
+            slot_of(q + 1, p1, par1, m1);
+            flag_next = __hip_atomic_load(flags + kFeatReady + 2 * p1 + par1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (staged) {
+            // Apply the staged steps.  Within one interaction the table rows do not read each other, so the reference's
+            // sequential update of the tables over the batch (rankfm/_rankfm.pyx:283-286, 313-326) is, for each table ROW, a walk
+            // over the interactions that touch it -- all rows at once, one row group per row with the row in registers, plain
+            // read and write.  The interactions that touch the row are found by the group's lanes together (one ballot per G
+            // staged steps); the row of v_if for tag q also carries w_if[q] (lane 0).
+            for (int r = gid; r < a.n_uf + a.n_if; r += gpb) {
+                const bool uf = r < a.n_uf;
+                if (uf ? !a.has_uf : !a.has_if) continue;
+                lds_float *row = lds + (size_t)r * F;                                  // v_uf rows, then v_if rows
+                const int xoff = 2 * FS + 1 + r;                                        // the step's coefficient of this table row
+                const lds_float *vec = stage + (uf ? FS : 0) + sub * KPL;               // updated v_i - v_j | updated v_u, this lane's dwords
+                float tr[KPL];
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) tr[k] = (sub + G * k < F) ? row[sub + G * k] : 0.0f;
+                float wq = uf ? 0.0f : lds[n_uf_f + n_if_f + (r - a.n_uf)];
+                int last = -1;                                                          // last staged step applied to w_if[q]
+                // one touching step: tr <- tr + eta (c v - reg_b tr), and the shrink of w_if over the untouched steps before it
+                auto one = [&](int s2, float c, const float (&v)[KPL], float rho_gap) {
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k) tr[k] += eta_f * (c * v[k] - reg_b * tr[k]);
+                    if (!uf) {
+                        wq = wq * rho_gap;
+                        wq += eta_f * (c - reg_b * wq);
+                        last = s2;
+                    }
+                };
+                for (int c64 = 0; c64 < gpb; c64 += 64) {
+                    // the steps that touch this row, found by the group's lanes together (one ballot per G staged steps, their LDS reads
+                    // in flight together)
+                    unsigned long long act = 0;
+                    for (int c0 = c64; c0 < gpb && c0 < c64 + 64; c0 += G) {
+                        const int mine = c0 + sub;
+                        const bool on = mine < gpb && stage[(size_t)mine * NSL + xoff] != 0.0f;
+                        unsigned long long bits;
+                        if constexpr (G == 64) bits = __ballot(on);
+                        else bits = (unsigned long long)group_ballot<G>(on);
+                        act |= bits << (c0 - c64);
+                    }
+                    // two touching steps per round: their coefficients, vectors and shrink powers are read together (one LDS round
+                    // trip), then applied one after the other
+                    while (act) {
+                        const int sA = c64 + __ffsll((long long)act) - 1;
+                        act &= act - 1;
+                        const bool two = act != 0;
+                        const int sB = two ? c64 + __ffsll((long long)act) - 1 : sA;
+                        if (two) act &= act - 1;
+                        const lds_float *stA = stage + (size_t)sA * NSL, *stB = stage + (size_t)sB * NSL;
+                        float vA[KPL], vB[KPL];
+                        lds_row_load<KPL>(vec + (size_t)sA * NSL, vA);
+                        lds_row_load<KPL>(vec + (size_t)sB * NSL, vB);
+                        const float cA = stA[2 * FS] * stA[xoff], cB = stB[2 * FS] * stB[xoff];
+                        const float rA = uf ? 1.0f : rho_pow[sA - last - 1], rB = uf ? 1.0f : rho_pow[sB - sA - (two ? 1 : 0)];
+                        one(sA, cA, vA, rA);
+                        if (two) one(sB, cB, vB, rB);
+                    }
                 }
-                s_stop = stop;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k)
+                    if (sub + G * k < F) row[sub + G * k] = tr[k];
+                if (!uf && sub == 0) lds[n_uf_f + n_if_f + (r - a.n_uf)] = wq * rho_pow[gpb - 1 - last];
             }
             __syncthreads();
-            if (s_stop) break;
-            // this batch is scored on the tables as published now
+            const unsigned long long tB = wall_clock64();
+            // publish the master copy (write-through to memory)
             for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
-                lds_tables[k] = __hip_atomic_load(table_ptr(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __syncthreads();
-            // a uniformly random row: a random segment (accepted with probability length / 32) and a random row of it
-            uint32_t h = rfm_mix32(a.epoch_key ^ rfm_mix32(((n * (unsigned)NP + (unsigned)p) * (unsigned)gpb + (unsigned)gid) * 0x9E3779B9U + 0x3C6EF372U + a.launch_index));
-            int4 d;
-            for (;;) {
-                d = a.seg_desc[rfm_draw_to_item(h, (uint32_t)a.n_segments)];
-                h = rfm_mix32(h + 0x632BE5ABU);
-                if ((int)rfm_draw_to_item(h, (uint32_t)kSegmentRows) < d.z) break;
-                h = rfm_mix32(h + 0x7F4A7C15U);
+                __hip_atomic_store(table_ptr(k), lds_tables[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            applied += (unsigned)gpb;
+            t_seg[0] += tB - tA;
+            t_seg[1] += wall_clock64() - tB;
+        }
+        const unsigned long long tC = wall_clock64();
+        // batch q into the staging area (everybody has finished reading batch q - 1: the barrier above / the first round)
+#pragma unroll
+        for (int j = 0; j < kPre; ++j) {
+            const unsigned d = (pre_dst[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
+            if (prefetch_ok && d != 0xFFFFu) stage[d] = pre[j];
+        }
+        for (size_t k = threadIdx.x + (prefetch_ok ? (size_t)kPre * blockDim.x : 0); k < batch_floats; k += blockDim.x)
+            stage[stage_index(k)] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        staged = true;
+        __syncthreads();
+        const unsigned long long tD = wall_clock64();
+        if (threadIdx.x == 0) flag_store(flags + kFeatConsumed + 2 * p + par, m + 1u);      // (the loads have returned: the slot is free)
+        t_seg[2] += tD - tC;
+        t_seg[3] += wall_clock64() - tD;
+    }
+    if (threadIdx.x == 0) {
+        if (applied) atomicAdd(a.error_flags + 2, applied);      // staged steps applied (rfm_fit_report.table_steps)
+        atomicAdd(a.error_flags + 4, (unsigned)(t_wait / 100));
+        atomicAdd(a.error_flags + 5, (unsigned)((wall_clock64() - t_begin) / 100));
+        for (int k = 0; k < 4; ++k) atomicAdd(a.error_flags + 8 + k, (unsigned)(t_seg[k] / 100));
+    }
+    // the launch is over: release the producers, wait until they have left, and leave the flags zero for the next launch
+    if (threadIdx.x == 0) {
+        flag_store(flags + kFeatStop, 1u);
+        for (unsigned spin = 0; flag_load(flags + kFeatExited) < (unsigned)NP && spin <= kFeatSpinLimit; ++spin) __builtin_amdgcn_s_sleep(8);
+        for (int k = 0; k < kFeatFlagWords; ++k) flag_store(flags + k, 0u);
+    }
+    return;
+}
+
+template <int G, int KPL, bool WARPB>
+__device__ __attribute__((noinline)) void feat_step_producer(const SgdArgs a, lds_float *lds, lds_int *s_stop_p) {
+    RFM_FEAT_LOCALS
+    for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
+    lds_float *stage = lds + n_tab;
+    __syncthreads();
+    // ---- a step producer ----------------------------------------------------------------------------------------------------
+    typedef RowStep<G, KPL, false, true, true, true, true, false, WARPB, false, 1> Train;
+    Train step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
+    const int p = (int)blockIdx.x - 1;
+    double ll_unused = 0.0;
+    unsigned draws_unused = 0;
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long t_wait = 0;
+    for (unsigned n = 0;; ++n) {
+        const unsigned par = n & 1u, m = n >> 1;
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            int stop = 0;
+            for (unsigned spin = 0;; ++spin) {           // the slot must have been emptied m times
+                if (flag_load(flags + kFeatStop)) { stop = 1; break; }
+                if (flag_load(flags + kFeatConsumed + 2 * p + par) >= m) break;
+                if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
             }
-            h = rfm_mix32(h ^ 0x85EBCA6BU);
-            const int32_t u = d.x, pos = d.y + (int32_t)rfm_draw_to_item(h, (uint32_t)d.z);
+            t_wait += wall_clock64() - t0;
+            *s_stop_p = stop;
+        }
+        __syncthreads();
+        if (*s_stop_p) break;
+        // this batch is scored on the tables as published now
+        for (int k = threadIdx.x; k < n_tab; k += blockDim.x)
+            lds_tables[k] = __hip_atomic_load(table_ptr(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        // a uniformly random row: a random segment (accepted with probability length / 32) and a random row of it
+        uint32_t h = rfm_mix32(a.epoch_key ^ rfm_mix32(((n * (unsigned)NP + (unsigned)p) * (unsigned)gpb + (unsigned)gid) * 0x9E3779B9U + 0x3C6EF372U + a.launch_index));
+        int4 d;
+        for (;;) {
+            d = a.seg_desc[rfm_draw_to_item(h, (uint32_t)a.n_segments)];
+            h = rfm_mix32(h + 0x632BE5ABU);
+            if ((int)rfm_draw_to_item(h, (uint32_t)kSegmentRows) < d.z) break;
+            h = rfm_mix32(h + 0x7F4A7C15U);
+        }
+        h = rfm_mix32(h ^ 0x85EBCA6BU);
+        const int32_t u = d.x, pos = d.y + (int32_t)rfm_draw_to_item(h, (uint32_t)d.z);
+        const int32_t i = a.csr_items[pos];
+        const float sw = a.sw_csr[pos];
+        const int64_t lo = a.csr_off[u], hi = a.csr_off[u + 1];
+        float vu[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) vu[k] = (sub + G * k < F) ? load_f32<true>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+        step.stage = stage + (size_t)gid * n_slot;
+        step(rfm_mix32(h ^ 0xC2B2AE35U), u, i, sw, lo, hi, vu, ll_unused, draws_unused);
+        __syncthreads();
+        g_float *dst = (g_float *)a.feat_ring + (size_t)(2 * p + par) * batch_floats;
+        for (size_t k = threadIdx.x; k < batch_floats; k += blockDim.x)
+            __hip_atomic_store(dst + k, stage[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // this wavefront's stores have been performed ...
+        __syncthreads();                                     // ... and everybody's, before the slot is announced
+        if (threadIdx.x == 0) flag_store(flags + kFeatReady + 2 * p + par, m + 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(a.error_flags + 6, (unsigned)(t_wait / 100));
+        atomicAdd(a.error_flags + 7, (unsigned)((wall_clock64() - t_begin) / 100));
+        __hip_atomic_fetch_add(flags + kFeatExited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+}
+
+// (inlined into the kernel: as a separate function its pointers would lose their global address space -- the struct is passed by
+// value -- and every access of the generic step would become a FLAT instruction)
+template <int G, int KPL, bool FRESH, bool WARPB>
+__device__ __forceinline__ void feat_generic_rows(const SgdArgs &a, lds_float *lds) {
+    RFM_FEAT_LOCALS
+    const int first_regular = trains ? 1 + NP : 0;
+    const int64_t group = a.single_group ? (int64_t)threadIdx.x / G : ((int64_t)blockIdx.x - first_regular) * gpb + threadIdx.x / G;
+    int64_t n_groups = a.single_group ? gpb : (int64_t)n_regular * gpb;
+    if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
+    double ll_acc = 0.0;
+    unsigned draw_acc = 0;
+    int64_t sp = a.pos_begin + (a.single_group ? 0 : group);
+    const int64_t stride = a.single_group ? 1 : n_groups;
+    bool active = sp < a.pos_end && (a.single_group ? group == 0 : group < n_groups);
+    bool have = false;
+    int32_t u = 0, begin = 0, len = 0, t = 0, len_bits = 0;
+    uint32_t seg_key = 0;
+    int64_t lo = 0, hi = 0;
+    float vu[KPL], vu0[KPL];
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
+    // ---- generic row loop (WARP, wide feature vectors, other row-group shapes; one group alone: both rows and tables) -----------
+    for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
+    __syncthreads();
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 0> Reg;
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 2> Both;
+    Reg step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
+    Both both(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
+    const bool train_here = a.single_group && !a.feat_frozen;          // one group alone trains the tables in its LDS
+    for (int iter = 0; __any(active); ++iter) {
+        if (trains) {
+            const int per = (n_tab + n_waves - 1) / n_waves, e0 = wave * per, e1 = e0 + per < n_tab ? e0 + per : n_tab;
+            for (int k = e0 + lane; k < e1; k += 64)
+                lds_tables[k] = __hip_atomic_load(table_ptr(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (active && !have) {
+            const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
+            const int4 d = a.seg_desc[seg];
+            u = d.x; begin = d.y; len = d.z;
+            lo = a.csr_off[u]; hi = a.csr_off[u + 1];
+            len_bits = (int32_t)rfm_perm_bits((uint32_t)len);
+            seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) {
+                vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                vu[k] = vu0[k];
+            }
+            t = 0;
+            have = true;
+        }
+        if (active) {
+            const int32_t pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);
             const int32_t i = a.csr_items[pos];
             const float sw = a.sw_csr[pos];
-            const int64_t lo = a.csr_off[u], hi = a.csr_off[u + 1];
-            float vu[KPL];
+            if (train_here) both(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+            else step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
+            if (++t == len) {
 #pragma unroll
-            for (int k = 0; k < KPL; ++k) vu[k] = (sub + G * k < F) ? load_f32<true>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
-            step.stage = stage + (size_t)gid * n_slot;
-            step(rfm_mix32(h ^ 0xC2B2AE35U), u, i, sw, lo, hi, vu, ll_unused, draws_unused);
-            __syncthreads();
-            float *dst = a.feat_ring + (size_t)(2 * p + par) * batch_floats;
-            for (size_t k = threadIdx.x; k < batch_floats; k += blockDim.x)
-                __hip_atomic_store(dst + k, stage[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // this wavefront's stores have been performed ...
-            __syncthreads();                                     // ... and everybody's, before the slot is announced
-            if (threadIdx.x == 0) flag_store(flags + kFeatReady + 2 * p + par, m + 1u);
+                for (int k = 0; k < KPL; ++k)
+                    if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                have = false;
+                sp += stride;
+                active = sp < a.pos_end;
+            }
         }
+    }
+    if (trains) {
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + kFeatExited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + kFeatDone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (train_here) {             // the one group trained the tables in its LDS: store them
+        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) *table_ptr(k) = lds_tables[k];
+    }
+    flush_counters(a, ll_acc, draw_acc);
+}
+
+template <int G, int KPL, bool FRESH, bool WARPB>
+__global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dynamic[];
+    lds_float *lds = (lds_float *)lds_dynamic;
+    __shared__ int s_stop;
+    RFM_FEAT_LOCALS
+    if (trains && blockIdx.x <= (unsigned)NP) {
+        if (blockIdx.x == 0) feat_table_trainer<G, KPL>(a, lds, (lds_int *)&s_stop);
+        else feat_step_producer<G, KPL, WARPB>(a, lds, (lds_int *)&s_stop);
         return;
     }
 
@@ -1869,59 +2051,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
       }
     }
 
-    // ---- generic row loop (WARP, wide feature vectors, other row-group shapes; one group alone: both rows and tables) -----------
-    for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
-    __syncthreads();
-    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 0> Reg;
-    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 2> Both;
-    Reg step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
-    Both both(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
-    const bool train_here = a.single_group && !a.feat_frozen;          // one group alone trains the tables in its LDS
-    for (int iter = 0; __any(active); ++iter) {
-        if (trains) {
-            const int per = (n_tab + n_waves - 1) / n_waves, e0 = wave * per, e1 = e0 + per < n_tab ? e0 + per : n_tab;
-            for (int k = e0 + lane; k < e1; k += 64)
-                lds_tables[k] = __hip_atomic_load(table_ptr(k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        if (active && !have) {
-            const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
-            const int4 d = a.seg_desc[seg];
-            u = d.x; begin = d.y; len = d.z;
-            lo = a.csr_off[u]; hi = a.csr_off[u + 1];
-            len_bits = (int32_t)rfm_perm_bits((uint32_t)len);
-            seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) {
-                vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
-                vu[k] = vu0[k];
-            }
-            t = 0;
-            have = true;
-        }
-        if (active) {
-            const int32_t pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);
-            const int32_t i = a.csr_items[pos];
-            const float sw = a.sw_csr[pos];
-            if (train_here) both(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
-            else step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
-            if (++t == len) {
-#pragma unroll
-                for (int k = 0; k < KPL; ++k)
-                    if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
-                have = false;
-                sp += stride;
-                active = sp < a.pos_end;
-            }
-        }
-    }
-    if (trains) {
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + kFeatDone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (train_here) {             // the one group trained the tables in its LDS: store them
-        for (int k = threadIdx.x; k < n_tab; k += blockDim.x) *table_ptr(k) = lds_tables[k];
-    }
-    flush_counters(a, ll_acc, draw_acc);
+    feat_generic_rows<G, KPL, FRESH, WARPB>(a, lds);
 }
 
 // host-side launcher table (rfm_sgd_inst_*.hip): [0..3] rows kernel {hogwild, hogwild+feat, serial, serial+feat},

@@ -168,7 +168,8 @@ def main():
                 rep2 = s.run(epochs=1, epoch_begin=1)
             g2 = s.weights_to_host()
             print("C4 run %d: table trainer: %d producers, %d staged steps in the last epoch = every %.0f-th row" % (
-                r, s.geometry()["table_producers"], s.geometry()["table_steps"], len(DATA["C4"]["pairs"]) / max(s.geometry()["table_steps"], 1)), flush=True)
+                r, s.geometry()["table_producers"], s.geometry()["table_steps"], len(DATA["C4"]["pairs"]) / max(s.geometry()["table_steps"], 1)),
+                  "  us: trainer waited / ran, producers waited / ran (summed)", s.geometry()["feat_diag"], flush=True)
             runs["C4:e1:%d" % r] = dict(ll=rep1["log_likelihood"].copy(), ms=rep1["sgd_kernel_ms"].copy(), norms={k: float(np.linalg.norm(g1[k])) for k in WEIGHTS})
             runs["C4:e2:%d" % r] = dict(ll=rep2["log_likelihood"].copy(), ms=rep2["sgd_kernel_ms"].copy(), norms={k: float(np.linalg.norm(g2[k])) for k in WEIGHTS})
             if r == 0:
