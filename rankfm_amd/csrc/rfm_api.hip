@@ -656,10 +656,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         // (sgd_features_kernel) -- resident workgroups like the others, not extra ones (a workgroup that had to wait for a free
         // CU would run its share after everybody else).  Measured on config 4's share (rfm_fit_report.feat_diag, profiles/r03_notes.md):
         // a producer stages a batch of 64 steps in ~33 us, the trainer applies one in ~12 us (its apply walk is bound by the LDS
-        // pipe of its CU): three or four producers keep it busy; with twelve they waited 77 % of the time.
+        // pipe of its CU): three producers keep it busy.  More only make the steps STALER -- a step is scored on the tables of its
+        // time, and on the 3000 x 2000 feature fixture two producers (one slot each) rank 0.9 point of hit_rate@10 better than four.
         if (use_segments && feat && !single_group && !feat_frozen) {
             const int64_t room = std::max<int64_t>(cap, 3);
-            n_producers = (int)std::max<int64_t>(1, std::min<int64_t>(4, ((int64_t)grid + 3) / 4));
+            n_producers = grid >= 64 ? 3 : (grid >= 4 ? 2 : 1);
             if (cfg->tune_table_producers > 0) n_producers = std::min(kFeatMaxProducers, cfg->tune_table_producers);
             if (grid + 1 + n_producers > room) grid = (int)std::max<int64_t>(1, room - 1 - n_producers);
             grid += 1 + n_producers;

@@ -1470,8 +1470,11 @@ __device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, ld
     unsigned flag_next = 0;                                   // (thread 0) the ready counter of the next batch, loaded ahead
     auto slot_of = [&](unsigned q, int &p, unsigned &par, unsigned &m) {
         p = NP > 0 ? (int)(q % (unsigned)NP) : 0;
+        // (ONE slot per producer: a staged step is scored on the tables of its time, and every batch that waits in a slot is a batch
+        // of stale steps -- with two slots each, three producers cost the 3000 x 2000 feature fixture 0.6 point of hit_rate@10 against
+        // one: profiles/r03_notes.md.  The second slot of the ring stays unused.)
         const unsigned n_p = NP > 0 ? q / (unsigned)NP : q;
-        par = n_p & 1u; m = n_p >> 1;
+        par = 0u; m = n_p;
     };
     if (threadIdx.x == 0 && NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // (diagnostics, rfm_fit_report.feat_diag: time this workgroup waited for a batch / ran in all, in 100 MHz ticks)
@@ -1635,7 +1638,7 @@ __device__ __attribute__((noinline)) void feat_step_producer(const SgdArgs a, ld
     const unsigned long long t_begin = wall_clock64();
     unsigned long long t_wait = 0;
     for (unsigned n = 0;; ++n) {
-        const unsigned par = n & 1u, m = n >> 1;
+        const unsigned par = 0u, m = n;                  // (one slot per producer: see the trainer)
         if (threadIdx.x == 0) {
             const unsigned long long t0 = wall_clock64();
             int stop = 0;
