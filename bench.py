@@ -256,7 +256,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, when collected
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s_hbm_bytes_per_launch" % args.config)
+                traffic = json.load(open(tpath)).get("%s%s_hbm_bytes_per_launch" % (args.config, "_stripes" if args.negative_stripes else ""))
             except Exception:
                 traffic = None
         if strong:
