@@ -173,7 +173,7 @@ def make_planted(n_users=6040, n_items=3706, rank=16, seed=0, mean_degree=165.0,
 
 def _planted_chunk(args):
     """top-deg items of a block of users under the planted score model (worker of make_planted_large)"""
-    seed, c, u0, u1, n_items, rank, deg, B, pop = args
+    seed, c, u0, u1, n_items, rank, deg, B, pop = args[:9]
     rng = np.random.default_rng([seed, 1000 + c])
     A = rng.normal(size=(u1 - u0, rank)).astype(np.float32)
     try:        # one BLAS thread per worker: a pool of workers x a 256-thread BLAS each thrashes a many-core host
@@ -191,7 +191,8 @@ def _planted_chunk(args):
     return users, top[keep].astype(np.int32)
 
 
-def make_planted_large(n_users, n_items, rank=16, seed=0, mean_degree=60.0, max_degree=1000, holdout=0.25, processes=None, chunk=2048):
+def make_planted_large(n_users, n_items, rank=16, seed=0, mean_degree=60.0, max_degree=1000, holdout=0.25, processes=None, chunk=2048,
+                       pop_weight=0.5):
     """make_planted's score model (3/4 <A_u, B_i> + popularity + Gumbel noise, clipped log-normal degrees) for problems of
     BASELINE config 2's size: user blocks are generated independently (seeded per block, in a process pool) and the top items of
     a row are found by partial selection instead of a full sort.  NOT the same random stream as make_planted -- the reference-minted
@@ -200,7 +201,8 @@ def make_planted_large(n_users, n_items, rank=16, seed=0, mean_degree=60.0, max_
     rng = np.random.default_rng([seed, 0])
     B = rng.normal(size=(n_items, rank)).astype(np.float32)
     pop = np.empty(n_items, dtype=np.float32)
-    pop[rng.permutation(n_items)] = -0.5 * np.log(np.arange(1, n_items + 1))
+    # (pop_weight: the popularity term is -pop_weight log(rank); 1.0 gives item frequencies close to the Zipf(1) of the BASELINE configs)
+    pop[rng.permutation(n_items)] = -pop_weight * np.log(np.arange(1, n_items + 1))
     deg = np.clip(rng.lognormal(np.log(mean_degree) - 0.5, 1.0, n_users), 10, min(max_degree, n_items // 2)).astype(np.int64)
     tasks = [(seed, c, u0, min(u0 + chunk, n_users), n_items, rank, deg[u0:u0 + chunk], B, pop)
              for c, u0 in enumerate(range(0, n_users, chunk))]

@@ -243,6 +243,23 @@ def test_hogwild_features_statistical_parity(oracle):
         assert 0.33 < np.linalg.norm(g[k]) / np.linalg.norm(o[k]) < 3.0, k
 
 
+def test_hogwild_warp_with_features_tracks_the_oracle(oracle):
+    """WARP with features at full concurrency: the generic row loop of sgd_features_kernel (candidate loop with the feature
+    projections) beside the table trainer and its step producers.  Same problem as the BPR test above; log-likelihood 3 %, accepted
+    draws 5 %, row norms 8 / 18 / 12 % like there (first two epochs from random weights), tables' scale only."""
+    prob = _problem(U=3000, I=2000, N=120_000, F=32, seed=21, n_uf=8, n_if=8, sigma=0.3)
+    g, rep, o, out = _both(oracle, prob, max_samples=6, epochs=2)
+    print("WARP + features: LL gpu/oracle - 1 =", rep["log_likelihood"] / out["ll64"] - 1.0, "draws", rep["n_draws"] / out["nsamp"].sum(axis=1) - 1.0,
+          "norms", {k: round(float(np.linalg.norm(g[k]) / np.linalg.norm(o[k])), 4) for k in WEIGHTS})
+    np.testing.assert_allclose(rep["log_likelihood"], out["ll64"], rtol=0.03)
+    np.testing.assert_allclose(rep["n_draws"], out["nsamp"].sum(axis=1), rtol=0.05)
+    for k, tol in (("v_u", 0.08), ("v_i", 0.18), ("w_i", 0.12)):
+        r = np.linalg.norm(g[k]) / np.linalg.norm(o[k])
+        assert abs(r - 1.0) <= tol, "|%s| gpu / oracle = %.4f" % (k, r)
+    for k in ("v_uf", "v_if", "w_if"):
+        assert np.isfinite(g[k]).all() and 0.33 < np.linalg.norm(g[k]) / np.linalg.norm(o[k]) < 3.0, k
+
+
 def test_hogwild_wide_feature_tables_use_smaller_workgroups(oracle):
     """k=128 with 40 + 40 tags: replica + two staging areas of a 1024-thread workgroup exceed the 160 KB of LDS, so the host
     halves the workgroup (rfm_api.hip, feat_waves) -- the 512-thread geometry of the feature kernel, its MFMA tiling with 8

@@ -1,8 +1,10 @@
 """CPU-only analysis: 2 / 4 / 8 user shards trained by the sequential oracle from the same epoch-start tables and merged like the
 ranks of rankfm_amd/distributed.py do (SharedTables.merge_scale), against sequential training of the whole data, on the
 MovieLens-1M-shaped planted problem.
-    python tools/merge_emulation.py [epochs] [learning_rate]
-Edit the (world, M factors, M biases) list at the bottom for other settings.  Numbers in profiles/r02_notes.md.
+    python tools/merge_emulation.py [epochs] [learning_rate] [zipf]
+`zipf`: a larger problem (40,000 x 8,000, 1.8 M rows) whose item frequencies follow the Zipf(1) of BASELINE config 4 instead of the
+MovieLens-shaped skew.  Edit the (world, M factors, M biases) list at the bottom for other settings.  Numbers in profiles/r02_notes.md /
+r03_notes.md.
 (test / analysis infrastructure: uses oracle/)"""
 import os
 import sys
@@ -19,9 +21,14 @@ from rankfm_amd.distributed import SHARED_NAMES, SharedTables, shard_boundaries,
 orc.build()
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 LR = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
-d = synthetic.make_planted(seed=0)
+ZIPF = len(sys.argv) > 3 and sys.argv[3] == "zipf"
+if ZIPF:
+    U, I, F = 40000, 8000, 20
+    d = synthetic.make_planted_large(U, I, seed=0, mean_degree=60.0, pop_weight=1.0)
+else:
+    U, I, F = 6040, 3706, 20
+    d = synthetic.make_planted(seed=0)
 pairs, test = d["train"], d["test"]
-U, I, F = 6040, 3706, 20
 N = len(pairs)
 csr = UserItemsCSR.from_pairs(pairs[:, 0], pairs[:, 1], U)
 w = synthetic.init_weights(U, I, F, seed=3)
@@ -46,7 +53,12 @@ out = orc.fit(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), z
 ll_seq = out["ll"]
 print("sequential: hit_rate@10 %.4f" % hit_rate(o["v_u"], o["v_i"], o["w_i"]), "LL/N", np.round(ll_seq / N, 4), flush=True)
 counts = np.bincount(pairs[:, 1], minlength=I)
-for world, M, MW in ((8, 32.0, 8.0), (8, 107.0, 27.0), (8, 213.0, 27.0), (8, 107.0, 107.0)):
+print("item frequency: top item %.2f %% of the rows, top 1 %% of the items %.1f %%" % (100.0 * counts.max() / N, 100.0 * np.sort(counts)[::-1][:max(I // 100, 1)].sum() / N))
+RULE = (3.2 / LR, 3.2 / LR / 4.0)          # the committed rule of SharedTables.set_merge_damping at >= 4 ranks
+SETTINGS = ((8,) + RULE, (8, 2 * RULE[0], RULE[1]), (8, RULE[0], RULE[0]), (8, 0.5 * RULE[0], 0.5 * RULE[1]))
+if len(sys.argv) > 4:                      # "M:MW,M:MW,..." in units of the committed rule's M
+    SETTINGS = tuple((8, float(x.split(":")[0]) * RULE[0], float(x.split(":")[1]) * RULE[0]) for x in sys.argv[4].split(","))
+for world, M, MW in SETTINGS:
     bounds = shard_boundaries(csr.offsets, world)
     shards = [take_user_shard(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), w["v_u"].copy(), bounds[r], bounds[r + 1]) for r in range(world)]
     ref = SharedTables({k: w[k].copy() for k in SHARED_NAMES}, torch.device("cpu"))
