@@ -546,6 +546,18 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
                                                                                               cfg->n_items, ws.error_flags);
         }
     }
+    // A saturated user (every item in the list) would make the rejection sampler of EVERY one of its rows run to its attempt limit
+    // before the error comes back -- minutes on a 70-row user -- so the verdict of the degree check is read before anything is
+    // launched (one 4-byte read-back per call that checked; the reference spins forever at rankfm/_rankfm.pyx:250-253).
+    if (cfg->plan_token <= 0) {
+        unsigned int flags = 0;
+        RFM_HIP(hipMemcpyAsync(&flags, ws.error_flags, sizeof flags, hipMemcpyDeviceToHost, stream));
+        RFM_HIP(hipStreamSynchronize(stream));
+        if (flags & 2u) {
+            if (rep) { rep->epochs_done = 0; rep->nonfinite_array = -1; rep->plan_token = 0; }
+            return RFM_ERR_USER_SATURATED;
+        }
+    }
     const bool single_group = use_segments && one_group_flag, fresh = (cfg->debug_flags & 2) != 0;
     const bool damp = !serial && !single_group && damp_m > 0.0f && N > 0;
 
