@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--configs", default="C2,C3,C4")
     ap.add_argument("--procs", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--damped", action="store_true")
+    ap.add_argument("--tune", default="", help="geometry overrides for the config-4 sessions: 'table_producers=6'")
     a = ap.parse_args()
     configs = a.configs.split(",")
     orc.build()
@@ -159,7 +160,7 @@ def main():
         lr = synthetic.CONFIGS["C4"]["learning_rate"]
         w0p = save_weights(DATA["C4"]["weights"], "c4_init")
         for r in range(a.runs):
-            s = session("C4", max_samples=1, seed=1492, learning_rate=lr)
+            s = session("C4", max_samples=1, seed=1492, learning_rate=lr, tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune.split(",") if kv})
             with gpu():
                 rep1 = s.run(epochs=1)
             g1 = s.weights_to_host()
