@@ -113,7 +113,9 @@ typedef struct rfm_fit_config {
                                       bit 3: no negative stripes even when `sampler` asks for them,
                                       bit 4: negative stripes for WARP as well (experiments; BPR only by default),
                                       bit 5: models with features: the dense feature tables are NOT trained (no table trainer); with
-                                             bit 0 the row loop of the features kernel runs on one row group -- parity tests */
+                                             bit 0 the row loop of the features kernel runs on one row group -- parity tests,
+                                      bit 6: BPR without features on full factor rows: the generic row step instead of the pipelined row
+                                             loop (experiments) */
     int32_t epoch_part_index;      /* with epoch_parts > 1: run only part k (0-based) of each epoch's visiting order -- lets a */
     int32_t epoch_parts;           /* multi-GPU caller exchange item deltas several times per epoch; 0 or 1 = whole epochs    */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
@@ -129,8 +131,8 @@ typedef struct rfm_fit_config {
                                       row loop of the stripe kernel with whole-catalogue draws */
     int32_t tune_hot_publications; /* publications of a hot row per epoch and workgroup (auto: 48) */
     int32_t tune_feature_waves;    /* wavefronts per workgroup of the features kernel, 2..16 (auto: 16) */
-    int32_t tune_table_producers;      /* features kernel: step-producer workgroups feeding the table trainer, 1..16 (auto: one per
-                                      16 row-loop workgroups, at most 12) */
+    int32_t tune_table_producers;      /* features kernel: step-producer workgroups feeding the table trainer, 1..16 (auto: 3 on a
+                                      full chip, 2 / 1 on small launches) */
     int32_t sampler;               /* RFM_SAMPLER_* (0 = the reference's uniform sampler) */
     int32_t tune_reserved[1];      /* must be 0 */
 } rfm_fit_config;
