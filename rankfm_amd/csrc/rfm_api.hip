@@ -605,14 +605,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // publication only costs them accuracy; one group alone keeps the stripes: that is the sequential form of the production
     // kernel the parity tests pin to the oracle.  Undamped Hogwild on skewed data needs every push published at once: notes.)
     const bool use_stripes = want_stripes && use_segments;
-    // The pipelined row loop with the reference's sampler (rfm_sgd.hpp, SMODE 2): BPR without features on full factor rows -- the
-    // production path of BASELINE configs 1 / 2.  Positive AND negative rows are gathered a row ahead, before the previous row's
-    // atomics; hot-row accumulators when the plan has hot rows; one group alone runs it sequentially (parity tests).  debug_flags
-    // bit 6 keeps the generic row step (experiments).
-    const bool use_pipe = use_segments && !feat && !use_stripes && cfg->max_samples == 1 && cfg->n_factors == shape->group * shape->kpl &&
-                          !(cfg->debug_flags & 64);
     const sgd_launch_fn launch = use_stripes ? shape->table()[10 + (fresh ? 1 : 0) + (use_hot ? 2 : 0)]
-                                 : use_pipe ? shape->table()[14 + (fresh ? 1 : 0)]
                                  : (use_hot && !feat) ? shape->table()[8 + (fresh ? 1 : 0)]
                                  : use_segments ? shape->table()[4 + (feat ? 1 : 0) + (fresh ? 2 : 0)]
                                                 : shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
@@ -627,7 +620,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     while (feat_waves > 2 && sizeof(float) * (feat_table_floats(cfg) + 8 + (size_t)feat_waves * (64 / shape->group) *
                                               (5 + 2 * (size_t)shape->group * shape->kpl + cfg->n_user_features + cfg->n_item_features)) > kLdsBytes)
         feat_waves /= 2;
-    const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : ((use_hot || use_stripes || use_pipe) ? 16 : 4));   // see sgd_segments_kernel
+    const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : ((use_hot || use_stripes) ? 16 : 4));   // see sgd_segments_kernel
     // stripe geometry: as many rows as the LDS left by the hot-row accumulators holds (at most 256: more rows mean longer
     // windows for the same combining), and a window in which a stripe row receives ~8 updates (groups x window / rows)
     int stripe_rows = 0, stripe_window = 1, stripe_rows_cap = 0;

@@ -297,14 +297,9 @@ __device__ __forceinline__ void sigmoid_terms(float x, float &log_sig, float &si
 //   TMODE    with LDSF: what the step updates (sgd_features_kernel).  0 = the rows only (v_u, v_i, w_i; the tables are a read-only
 //            copy), 1 = the tables only (the table trainer: plain read-modify-write on the master copy, groups of a wavefront one
 //            after the other), 2 = both (one group alone: the reference's sequential step)
-// SMODE (segments kernel without features): 0 the generic row step; 1 negative stripes; 2 the pipelined row loop with the
-// reference's sampler (whole-catalogue draws, one set of atomics per negative) -- both 1 and 2 are planned for FULL factor rows
-// only (F == G * KPL, a compile-time constant: no per-dword predicates) and take the positive item's row fetched a row ahead
-// (PosRow); 2 takes the negative's row a row ahead as well (NegRow).
 template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false, bool WARPB = true,
-          int SMODE = 0, int TMODE = 0>
+          bool STRIPE = false, int TMODE = 0>
 struct RowStep {
-    static constexpr bool STRIPE = SMODE == 1, FULL = SMODE != 0;
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
     const int F;
@@ -322,9 +317,7 @@ struct RowStep {
     // pending sum is at most 64 touches of steps eta * sample_weight * |v|, i.e. < 0.3 at eta = 0.1 and unit weights.
     lds_int *hot_acc = nullptr;
     lds_int *hot_accw = nullptr;
-    lds_int *hot_cnt = nullptr;      // [n_hot] publication period of each slot (SgdArgs::hot_period, copied by the kernel: a global
-                                     // load behind the row's atomics would wait for every one of them -- vmcnt returns in order)
-    float mult1 = 1.0f;              // a.multiplier[1]: BPR's multiplier (:269 with sampled == 1), loaded once per kernel (FULL)
+    lds_int *hot_cnt = nullptr;
     float kHotScale = 16777216.0f, kHotUnit = 1.0f / 16777216.0f;
     __device__ __forceinline__ void hot_add(lds_int *p, float v) const {
         __hip_atomic_fetch_add(p, __float2int_rn(v * kHotScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -433,13 +426,13 @@ struct RowStep {
     }
 
     __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_, TabPtr v_uf, TabPtr v_if, TabPtr w_if)
-        : a(args), sub(sub_), F(FULL ? G * KPL : args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
-    // (stripe / pipelined launches are planned for full factor rows only: the factor count is the compile-time constant G * KPL there)
+        : a(args), sub(sub_), F(STRIPE ? G * KPL : args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
+    // (stripe launches are planned for full factor rows only: the factor count is the compile-time constant G * KPL there)
 
     __device__ __forceinline__ int dword_f(int k) const { return sub + G * k; }
     // (stripe launches are planned for FULL factor rows only, F == G * KPL: no per-dword predicate -- a v_cmp, an exec-mask
     //  save and a branch around every load, atomic and LDS update of the row loop otherwise)
-    __device__ __forceinline__ bool dword_ok(int k) const { return FULL || dword_f(k) < F; }
+    __device__ __forceinline__ bool dword_ok(int k) const { return STRIPE || dword_f(k) < F; }
 
     template <bool FR>
     __device__ __forceinline__ void load_row(const float *base, float (&r)[KPL]) const {
@@ -571,83 +564,24 @@ struct RowStep {
 
     // the positive item's row, bias and step scale fetched ahead of the row's turn (segments kernel, STRIPE): rows of a segment
     // depend on each other only through v_u, which lives in registers, so the next row's gathers overlap the current row
-    // (with a padded bias line `w` holds the line's dwords AS LOADED, bias in the even lanes and step scale in the odd ones, and
-    //  `scale` is unused -- pos_w / pos_scale_of broadcast them when the row is consumed: a shuffle here would wait for the load,
-    //  and for everything issued before it)
     struct PosRow { float v[KPL]; float w, scale; };
     __device__ __forceinline__ void prefetch_pos(int32_t it, PosRow &p) const {
         load_row<FRESH>(a.v_i + (size_t)it * F, p.v);
-        if (FULL || a.scale_in_pad) {
+        if (STRIPE || a.scale_in_pad) {
             // lanes 0 / 1 of the group read dwords 0 / 1 of the item's line: bias and step scale in ONE request
-            // (ONE destination register: a second copy of the loaded value would be a move that waits for the load)
-            p.w = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride + (sub & 1));
+            const float x = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride + (sub & 1));
+            const int base = (threadIdx.x & 63) - sub;
+            p.w = __shfl(x, base);
+            p.scale = __shfl(x, base + 1);
         } else {
             p.w = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
             p.scale = a.pos_scale ? a.pos_scale[it] : 1.0f;
-        }
-    }
-    __device__ __forceinline__ float pos_w(const PosRow &p) const {
-        if (!(FULL || a.scale_in_pad)) return p.w;
-        if constexpr (G == 16) return dpp_mov<0x150>(p.w);                      // row_share:0
-        else return __shfl(p.w, (int)(threadIdx.x & 63) - sub);
-    }
-    __device__ __forceinline__ float pos_scale_of(const PosRow &p) const {
-        if (!(FULL || a.scale_in_pad)) return p.scale;
-        if constexpr (G == 16) return dpp_mov<0x151>(p.w);                      // row_share:1
-        else return __shfl(p.w, (int)(threadIdx.x & 63) - sub + 1);
-    }
-
-    // the NEGATIVE of a row drawn and fetched ahead of the row's turn (SMODE 2, BPR): the draw stream is keyed by (row, attempt) and
-    // the membership test reads the user's list out of registers (load_ulist), so the next row's negative is known a row early;
-    // its gathers are then issued BEFORE the current row's atomics.  That matters twice: the row's own chain holds no memory round
-    // trip any more, and -- vmcnt counts loads and returnless atomics alike and returns in order -- a load issued behind the
-    // atomics could only be waited for together with their acknowledgements from the memory side.  ok == false (the user's list
-    // is too long for the registers): the row draws and fetches its negative itself.
-    struct NegRow { float v[KPL]; float w; int32_t j; bool ok; };
-    __device__ __forceinline__ void prefetch_neg(int64_t lo, int64_t hi, uint32_t row_key, NegRow &n) const {
-        n.ok = ulist_ok;
-        if (ulist_ok) {
-            uint32_t attempt = 0;
-            int srow;
-            n.j = next_negative(lo, hi, row_key, attempt, srow);
-            load_row<FRESH>(a.v_i + (size_t)n.j * F, n.v);
-            n.w = load_f32<FRESH>(a.w_i + (size_t)n.j * a.w_stride);
-        }
-    }
-
-    // The item-side atomics of a row, held back until the NEXT row's turn (SMODE 2): the kernel waits for memory at ONE point per
-    // row -- the top, for the gathers issued a row earlier -- then issues the previous row's atomics and the next row's gathers
-    // back to back, and all of them have the row's arithmetic to complete in.  (Issued at the row's end instead, the atomics'
-    // acknowledgements from the memory side would be what the next wait waits for: vmcnt counts loads and returnless atomics alike
-    // and returns in order.)  pos == false: the positive went into a hot slot's LDS sums.
-    struct Pending { float d_i[KPL], d_j[KPL], dwi, dwj; int32_t i, j; bool pos, any; };
-    __device__ __forceinline__ void publish(Pending &p) const {
-        if (p.any) {
-            if (p.pos) {
-                float *pv = a.v_i + (size_t)p.i * F + sub;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) atomic_add_f32(pv + G * k, p.d_i[k]);
-                if (sub == 0) atomic_add_f32(a.w_i + (size_t)p.i * a.w_stride, p.dwi);
-            }
-            float *pv = a.v_i + (size_t)p.j * F + sub;
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) atomic_add_f32(pv + G * k, p.d_j[k]);
-            if (sub == 0) atomic_add_f32(a.w_i + (size_t)p.j * a.w_stride, p.dwj);
-            p.any = false;
         }
     }
 
     // `vu` holds v_u[u] on entry; with VU_REGS it holds the updated row on exit
     __device__ __forceinline__ void operator()(uint32_t row_key, int32_t u, int32_t i, float sw, int64_t lo, int64_t hi,
                                                float (&vu)[KPL], double &ll_acc, unsigned &draw_acc, const PosRow *pre = nullptr) const {
-        Pending none;
-        none.any = false;
-        run(row_key, u, i, sw, lo, hi, vu, ll_acc, draw_acc, pre, nullptr, none, false);
-    }
-    // (`pd` / `defer`: SMODE 2 -- the row's global atomics are left in `pd` for publish() instead of being issued)
-    __device__ __forceinline__ void run(uint32_t row_key, int32_t u, int32_t i, float sw, int64_t lo, int64_t hi,
-                                        float (&vu)[KPL], double &ll_acc, unsigned &draw_acc, const PosRow *pre,
-                                        const NegRow *preneg, Pending &pd, const bool defer) const {
         uint32_t attempt = 0;
         float A[KPL];
         XV xu, xi, xj, xc;
@@ -660,9 +594,9 @@ struct RowStep {
         int slot = -1;
         float pos_scale_i = 1.0f;
         if constexpr (!SERIAL) {
-            if (FULL || a.pos_scale) {
-                // (stripe / pipelined launches always carry bias and step scale in the item's padded line: scale 1 when nothing is damped)
-                pos_scale_i = (FULL || pre) ? pos_scale_of(*pre) : a.pos_scale[i];
+            if (STRIPE || a.pos_scale) {
+                // (stripe launches always carry bias and step scale in the item's padded line: scale 1 when nothing is damped)
+                pos_scale_i = (STRIPE || pre) ? pre->scale : a.pos_scale[i];
                 if constexpr (HOT) {
                     if (pos_scale_i >= 2.0f) {
                         slot = (int)(pos_scale_i * 0.5f) - 1;
@@ -724,11 +658,11 @@ struct RowStep {
             for (int k = 0; k < KPL; ++k) part += (vu[k] + A[k]) * (vi[k] - vj[k]) + Bi[k] * vu[k];
             min_pu = (wi - wj) + scalar + group_sum<G>(part);
         } else {
-        if (FULL && pre) {
-            // (no features here: the utility is bias + dot product, on the prefetched row)
+        if (STRIPE && pre) {
+            // (STRIPE has no features: the utility is bias + dot product, on the prefetched row)
 #pragma unroll
             for (int k = 0; k < KPL; ++k) vi[k] = pre->v[k];
-            wi = pos_w(*pre);
+            wi = pre->w;
             if constexpr (HOT) {
                 if (slot >= 0) {
 #pragma unroll
@@ -737,14 +671,12 @@ struct RowStep {
                     wi += (float)hot_accw[slot] * kHotUnit;
                 }
             }
-            if constexpr (STRIPE) {
-              if (sn_rows > 0) {
+            if (sn_rows > 0) {
                 const float c = kHotUnit * sn_inv_rows;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
                     if (dword_ok(k)) vi[k] += (float)sn_sum[dword_f(k)] * c;
                 wi += (float)sn_sum[F] * (c * kSumCoarse);
-              }
             }
             float part = 0.0f;
 #pragma unroll
@@ -753,22 +685,8 @@ struct RowStep {
         } else
         ut_ui = utility(vu, A, i, vi, Bi, wi, slot, &xi);    // :239
 
-        // the negative drawn and fetched a row ahead (SMODE 2, BPR: the one draw does not depend on any score)
-        bool have_neg = false;
-        if constexpr (SMODE == 2 && !WARPB) {
-            if (preneg && preneg->ok) {
-                have_neg = true;
-                j = preneg->j; wj = preneg->w;
-                float part = 0.0f;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) { vj[k] = preneg->v[k]; part += vu[k] * vj[k]; }
-                min_pu = ut_ui - (wj + group_sum<G>(part));                   // :256-257
-                sampled = 1;
-            }
-        }
         // WARP sampling loop (:244-264); BPR is max_samples == 1
         // first draw (all of BPR): one candidate at a time
-        if (!have_neg)
         for (; s <= ((BATCH_WARP || (!SERIAL && !FEAT && !WARPB)) ? 1 : a.max_samples); ++s) {
             int crow;
             const int32_t cand = next_negative(lo, hi, row_key, attempt, crow);
@@ -849,7 +767,7 @@ struct RowStep {
             }
         }
         const float pu = min_pu;                                          // :267-268
-        const float multiplier = (FULL && !WARPB && !SERIAL) ? mult1 : a.multiplier[sampled];   // :269 (integer division inside the log)
+        const float multiplier = a.multiplier[sampled];                   // :269 (integer division inside the log)
         float log_sig, d_outer;
         sigmoid_terms(pu, log_sig, d_outer);                              // :270, :276
         if (UPD_ROWS && sub == 0) { ll_acc += (double)log_sig; draw_acc += (unsigned)sampled; }
@@ -857,14 +775,14 @@ struct RowStep {
         const float eta = a.eta, reg_a = a.reg_a, reg_b = a.reg_b;
         float eta_u = eta, eta_i = eta, eta_f = eta;
         if constexpr (!SERIAL) {
-            if constexpr (FULL) eta_u = eta * user_scale;            // (per segment: load_ulist)
+            if constexpr (STRIPE) eta_u = eta * user_scale;          // (per segment: load_ulist)
             else eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
             eta_i = eta * pos_scale_i;
             if constexpr (!LDSF) eta_f = eta * a.feat_scale;
         }
         float nvu[KPL], dij[KPL];     // updated v_u, updated (v_i - v_j) (feature paths)
-        if constexpr (FULL && !SERIAL && !FEAT && VU_REGS) {
-            // The same arithmetic as the generic code below, arranged for the stripe / pipelined instantiations: every delta first, then ONE
+        if constexpr (STRIPE && !SERIAL && !FEAT && VU_REGS) {
+            // The same arithmetic as the generic code below, arranged for the stripe instantiations: every delta first, then ONE
             // branch per publication target (hot slot or atomics for the positive, stripe row or atomics for the negative)
             // instead of one per dword.
             float d_i[KPL], d_j[KPL];
@@ -879,25 +797,17 @@ struct RowStep {
             }
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);           // :279
             const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);            // :280
-            if (SMODE == 2 && defer) {
-                // (the global atomics wait for the next row's turn: publish)
-                pd.i = i; pd.j = j; pd.any = true; pd.pos = !(HOT && slot >= 0);
-                pd.dwi = dwi; pd.dwj = dwj;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) { pd.d_i[k] = d_i[k]; pd.d_j[k] = d_j[k]; }
-            }
             if (HOT && slot >= 0) {
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) hot_add(hot_acc + slot * F + dword_f(k), d_i[k]);
                 if (sub == 0) hot_add(hot_accw + slot, dwi);
-            } else if (!(SMODE == 2 && defer)) {
+            } else {
                 float *pv = a.v_i + (size_t)i * F + sub;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) atomic_add_f32(pv + G * k, d_i[k]);
                 if (sub == 0) atomic_add_f32(a.w_i + (size_t)i * a.w_stride, dwi);
             }
-            if (SMODE == 2 && defer) {
-            } else if (STRIPE && jrow >= 0) {
+            if (jrow >= 0) {
                 lds_int *pd = sn_delta + jrow * (F + 1) + sub, *ps = sn_sum + sub;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) {
@@ -959,7 +869,7 @@ struct RowStep {
             if (slot >= 0) {
                 // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it
                 // (a keyed coin with probability 1 / period instead of a shared counter: no LDS round trip on the row's path)
-                if (__umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)hot_cnt[slot]) == 0u) {     // probability 1 / period
+                if (__umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)a.hot_period[slot]) == 0u) {     // probability 1 / period
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
@@ -1157,34 +1067,27 @@ static __global__ void __launch_bounds__(256) hot_reduce_kernel(const SgdArgs a)
 // the window ends every stripe row is published with ONE set of atomics however many updates it received -- with
 // 64 groups x 32 rows on 256 stripe rows about eight.  That takes the negative item's 4 + 1 memory-side atomic requests per
 // update (of ~10, the kernel's bound: DESIGN.md section 7) down to ~0.6, and the negative's row reads from 5 to ~0.6.
-//
-// SMODE 2 (production BPR with the reference's sampler, full factor rows): the same pipelined row loop as the stripe kernel --
-// segment rows in registers, positive item's row a row ahead -- with whole-catalogue draws, and with the NEGATIVE's row a row
-// ahead too (RowStep::NegRow): all of a row's gathers are issued before the previous row's atomics.
-template <int G, int KPL, bool FRESH, bool HOT = false, bool WARPB = true, int SMODE = 0>
-__global__ void __launch_bounds__((HOT || SMODE != 0) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
+template <int G, int KPL, bool FRESH, bool HOT = false, bool WARPB = true, bool STRIPE = false>
+__global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
     constexpr bool FEAT = false;        // (models with features run sgd_features_kernel)
-    constexpr bool STRIPE = SMODE == 1, FULL = SMODE != 0, PIPE = SMODE == 2;
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
     if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
-    const int F = FULL ? G * KPL : a.n_factors;
+    const int F = STRIPE ? G * KPL : a.n_factors;
     extern __shared__ __attribute__((aligned(16))) float lds_tables[];
     lds_float *lds = (lds_float *)lds_tables;
-    typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, WARPB, SMODE> Step;
+    typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, WARPB, STRIPE> Step;
     Step step(a, sub, a.v_uf, a.v_if, a.w_if);
-    if constexpr (FULL) step.mult1 = a.multiplier[1];
     if constexpr (HOT) {
-        // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] publication periods
-        const int n_acc = a.n_hot * (F + 1);
+        // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] touch counters
+        const int n_acc = a.n_hot * (F + 2);
         for (int k = threadIdx.x; k < n_acc; k += blockDim.x) lds_tables[k] = 0.0f;
+        __syncthreads();
         step.hot_acc = (lds_int *)lds;
         step.hot_accw = (lds_int *)(lds + a.n_hot * F);
         step.hot_cnt = (lds_int *)(lds + a.n_hot * (F + 1));
-        for (int k = threadIdx.x; k < a.n_hot; k += blockDim.x) step.hot_cnt[k] = a.hot_period[k];
-        __syncthreads();
     }
     if constexpr (HOT || STRIPE) {
         // steps scale with learning rate x sample weight: unit 2^-24 at the defaults (eta 0.1, weights <= 1)
@@ -1268,11 +1171,6 @@ __global__ void __launch_bounds__((HOT || SMODE != 0) ? 1024 : 256) sgd_segments
     int32_t seg_item[SEGR], seg_pos[SEGR];
     float seg_sw[SEGR];
     typename Step::PosRow cur_pos, next_pos;
-    cur_pos.scale = next_pos.scale = 1.0f;
-    typename Step::NegRow cur_neg, next_neg;
-    typename Step::Pending pend;
-    cur_neg.ok = next_neg.ok = false;
-    pend.any = false;
     const int lane_base = lane - sub;
     // row t of the segment: register t / G of lane t % G (the register index is selected, not indexed: registers stay registers).
     // 16-lane groups are DPP rows: the registers are ROTATED one lane per processed row (seg_rotate), so the current row is
@@ -1285,18 +1183,18 @@ __global__ void __launch_bounds__((HOT || SMODE != 0) ? 1024 : 256) sgd_segments
     };
     auto seg_get = [&](const int32_t (&r)[SEGR], int tt, bool next = false) {
         const int32_t x = seg_pick(r, tt);
-        if constexpr (G == 16 && FULL) return next ? dpp_movi<0x151>(x) : dpp_movi<0x150>(x);      // row_share:1 / row_share:0
+        if constexpr (G == 16 && STRIPE) return next ? dpp_movi<0x151>(x) : dpp_movi<0x150>(x);      // row_share:1 / row_share:0
         else return __shfl(x, lane_base + (int)((unsigned)tt % G));
     };
     auto seg_getf = [&](const float (&r)[SEGR], int tt) {
         float x = r[0];
 #pragma unroll
         for (int k = 1; k < SEGR; ++k) x = ((unsigned)tt / G == (unsigned)k) ? r[k] : x;
-        if constexpr (G == 16 && FULL) return dpp_mov<0x150>(x);
+        if constexpr (G == 16 && STRIPE) return dpp_mov<0x150>(x);
         else return __shfl(x, lane_base + (int)((unsigned)tt % G));
     };
     auto seg_rotate = [&]() {
-        if constexpr (G == 16 && FULL) {
+        if constexpr (G == 16 && STRIPE) {
 #pragma unroll
             for (int k = 0; k < SEGR; ++k) {
                 seg_item[k] = dpp_movi<0x12F>(seg_item[k]);       // row_ror:15: lane s takes lane s + 1
@@ -1340,13 +1238,13 @@ __global__ void __launch_bounds__((HOT || SMODE != 0) ? 1024 : 256) sgd_segments
             seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
-                vu0[k] = (FULL || sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                vu0[k] = (STRIPE || sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
                 vu[k] = vu0[k];
             }
             t = 0;
             have = true;
             step.load_ulist(lo, hi);
-            if constexpr (FULL) {
+            if constexpr (STRIPE) {
                 // the segment's rows in visiting order, held across the lanes (row t in lane t % G, register t / G): item,
                 // sample weight and CSR position come out of registers for the rest of the segment
 #pragma unroll
@@ -1357,39 +1255,20 @@ __global__ void __launch_bounds__((HOT || SMODE != 0) ? 1024 : 256) sgd_segments
                     seg_sw[k] = a.sw_csr[seg_pos[k]];
                 }
                 step.prefetch_pos(seg_get(seg_item, 0), next_pos);
-                if constexpr (PIPE) step.prefetch_neg(lo, hi, rfm_row_key(a.epoch_key, (uint32_t)seg_get(seg_pos, 0)), next_neg);
             }
         }
-        // The row's ONE wait for memory (SMODE 2): its own gathers, issued a row ago (or just now, for a segment's first row), and the
-        // atomics of the row before the previous one.  (Unconditional, so that the compiler's own wait-count bookkeeping sees every
-        // path pass it: a wait it places itself further down would wait for the atomics and gathers issued in between.)
-        if constexpr (PIPE) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0)
         if (active) {
             int32_t pos, i;
             float sw;
-            if constexpr (FULL) {
+            if constexpr (STRIPE) {
                 pos = seg_get(seg_pos, t); i = seg_get(seg_item, t); sw = seg_getf(seg_sw, t);
                 cur_pos = next_pos;
-                if constexpr (PIPE) {
-                    cur_neg = next_neg;
-                    // (behind the row's one wait: the previous row's atomics, then the next row's gathers, back to back)
-                    step.publish(pend);
-                }
                 // (one group alone is a sequential program: a repeated (user, item) row must see the previous row's update of
-                // the same item, so nothing is fetched ahead there -- SMODE 1 fetches the row in place, SMODE 2 fetches the next row
-                // behind this row's fence, below: no load of the sequential form lands in a register the pipelined form reads)
-                if constexpr (PIPE) {
-                    if (!a.single_group && t + 1 < len) {                                               // overlaps this row
-                        step.prefetch_pos(seg_get(seg_item, t + 1, true), next_pos);
-                        step.prefetch_neg(lo, hi, rfm_row_key(a.epoch_key, (uint32_t)seg_get(seg_pos, t + 1, true)), next_neg);
-                    }
-                } else {
-                    if (a.single_group) step.prefetch_pos(i, cur_pos);
-                    else if (t + 1 < len) step.prefetch_pos(seg_get(seg_item, t + 1, true), next_pos);     // overlaps this row
-                }
+                // the same item, so nothing is fetched ahead there)
+                if (a.single_group) step.prefetch_pos(i, cur_pos);
+                else if (t + 1 < len) step.prefetch_pos(seg_get(seg_item, t + 1, true), next_pos);     // overlaps this row
                 seg_rotate();
-                step.run(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc, &cur_pos, PIPE ? &cur_neg : nullptr,
-                         pend, PIPE && !a.single_group);
+                step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc, &cur_pos);
             } else {
                 pos = begin + (int32_t)rfm_perm((uint32_t)t, (uint32_t)len, (uint32_t)len_bits, seg_key);
                 i = a.csr_items[pos];
@@ -1397,24 +1276,13 @@ __global__ void __launch_bounds__((HOT || SMODE != 0) ? 1024 : 256) sgd_segments
                 step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
             }
             if (++t == len) {
-                if constexpr (PIPE) step.publish(pend);
                 // one write-back per segment; other segments of a heavy user may be in flight, so add the delta
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
-                    if (FULL || sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                    if (STRIPE || sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
                 have = false;
                 sp += stride;
                 active = sp < a.pos_end;
-            }
-            if constexpr (PIPE) {
-                // (one group alone is a sequential program: the next row reads what this one wrote)
-                if (a.single_group) {
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-                    if (have) {
-                        step.prefetch_pos(seg_get(seg_item, t), next_pos);
-                        step.prefetch_neg(lo, hi, rfm_row_key(a.epoch_key, (uint32_t)seg_get(seg_pos, t)), next_neg);
-                    }
-                }
             }
         }
     }
@@ -1762,7 +1630,7 @@ __device__ __attribute__((noinline)) void feat_step_producer(const SgdArgs a, ld
     lds_float *stage = lds + n_tab;
     __syncthreads();
     // ---- a step producer ----------------------------------------------------------------------------------------------------
-    typedef RowStep<G, KPL, false, true, true, true, true, false, WARPB, 0, 1> Train;
+    typedef RowStep<G, KPL, false, true, true, true, true, false, WARPB, false, 1> Train;
     Train step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     const int p = (int)blockIdx.x - 1;
     double ll_unused = 0.0;
@@ -1849,8 +1717,8 @@ __device__ __forceinline__ void feat_generic_rows(const SgdArgs &a, lds_float *l
     // ---- generic row loop (WARP, wide feature vectors, other row-group shapes; one group alone: both rows and tables) -----------
     for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
     __syncthreads();
-    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, 0, 0> Reg;
-    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, 0, 2> Both;
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 0> Reg;
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 2> Both;
     Reg step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     Both both(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     const bool train_here = a.single_group && !a.feat_frozen;          // one group alone trains the tables in its LDS
@@ -1964,7 +1832,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
             hot_unit = range / 16777216.0f;
         }
         __syncthreads();
-        typedef RowStep<G, KPL, false, true, true, FRESH, true, false, false, 0, 0> Reg;
+        typedef RowStep<G, KPL, false, true, true, FRESH, true, false, false, false, 0> Reg;
         Reg step(a, sub, lds, lds, lds);                               // (draws, membership test, user damping; its tables are unused)
         const lds_float *uf_lane = t_uf + sub * KPL, *if_lane = t_if + sub * KPL;
         const int lane_base = lane - sub;
@@ -2191,7 +2059,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
 
 // host-side launcher table (rfm_sgd_inst_*.hip): [0..3] rows kernel {hogwild, hogwild+feat, serial, serial+feat},
 // [4..7] segments kernel {plain, features kernel, fresh, features kernel fresh}, [8..9] segments kernel with hot-row accumulators {plain, fresh},
-// [10..13] segments kernel with negative stripes {plain, fresh, hot, hot+fresh}, [14..15] pipelined row loop, reference's sampler {plain, fresh}
+// [10..13] segments kernel with negative stripes {plain, fresh, hot, hot+fresh}
 typedef void (*sgd_launch_fn)(const SgdArgs &, int grid, hipStream_t);
 
 }  // namespace rfm
