@@ -1466,6 +1466,11 @@ __device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, ld
     }
     const bool prefetch_ok = (size_t)gpb * NSL < 0xFFFFu;    // (else every dword of a batch takes the direct path below)
     unsigned applied = 0;
+    // A floor under the number of steps applied per launch -- one batch, or every 512th row of the launch -- so that a launch
+    // too short for the trainer's pace (small problems: the row loops are done before the second batch arrives) still trains
+    // its tables; the trainer then outlasts the row loops by a few batches.  Large launches apply far more than this (config
+    // 4: every ~240th row) and stop with the row loops, i.e. their step count depends on timing.
+    const unsigned quota = (unsigned)fmax((double)gpb, (double)a.n_rows * (double)(a.pos_end - a.pos_begin) / fmax(1.0, (double)a.n_segments) / 512.0);
     bool staged = false;                                      // LDS holds a batch that has not been applied yet
     unsigned flag_next = 0;                                   // (thread 0) the ready counter of the next batch, loaded ahead
     auto slot_of = [&](unsigned q, int &p, unsigned &par, unsigned &m) {
@@ -1488,10 +1493,10 @@ __device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, ld
             int stop = 0;
             // (the row loops' end is looked at every 16th batch and whenever the trainer has to wait: the producers stay ahead of
             // it, so without the periodic look it would never stop)
-            if ((q & 15u) == 0u && __hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) stop = 1;
+            if ((q & 15u) == 0u && applied >= quota && __hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) stop = 1;
             const unsigned long long t0 = wall_clock64();
             for (unsigned spin = 0; !stop && (NP == 0 || flag_next < m + 1u); ++spin) {
-                if (__hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) { stop = 1; break; }
+                if (applied >= quota && __hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) { stop = 1; break; }
                 if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }      // (never observed: a hang guard)
                 __builtin_amdgcn_s_sleep(4);
                 if (NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady + 2 * p + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
