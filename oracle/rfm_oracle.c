@@ -150,6 +150,10 @@ typedef struct {
      * trainer, which trains the tables on a sample of the rows while every row reads them (rfm_sgd.hpp, sgd_features_kernel) */
     int32_t table_every;
     float table_step;
+    /* analysis only: the first `table_head_rows` visited rows of the FIRST epoch of the call use `table_head_every` instead of
+     * `table_every` (0 rows = no head) -- a sequential stand-in for a slow, table-friendly opening of the first epoch */
+    int32_t table_head_every;
+    int64_t table_head_rows;
 } rfm_oracle_params;
 
 /* return codes */
@@ -260,7 +264,8 @@ static int fit_impl(const rfm_oracle_params *p,
             const float *xi = x_if + (size_t)i * Q, *xj = x_if + (size_t)j * Q, *xu = x_uf + (size_t)u * P;
             /* (analysis option; always 1 for the reference.  table_every < 0: the tables are frozen -- what the engine's row loop does
              *  when its table trainer is switched off, debug_flags bit 5) */
-            const int do_tab = p->table_every < 0 ? 0 : (p->table_every <= 1 || r % p->table_every == 0);
+            const int tab_every = (e == 0 && r < p->table_head_rows) ? p->table_head_every : p->table_every;
+            const int do_tab = tab_every < 0 ? 0 : (tab_every <= 1 || r % tab_every == 0);
             const float eta_t = p->table_step > 0.0f ? eta * p->table_step : eta;
             if (p->has_if && do_tab)                                               /* :283-286 */
                 for (int q = 0; q < Q; ++q) {

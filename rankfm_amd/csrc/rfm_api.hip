@@ -834,7 +834,35 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             u_begin = units * cfg->epoch_part_index / cfg->epoch_parts;
             u_end = units * (cfg->epoch_part_index + 1) / cfg->epoch_parts;
         }
-        for (int64_t p0 = u_begin; p0 < u_end; p0 += units_per_launch, ++window) {
+        // The opening of a fit with features (absolute epoch 0, its first rows): the dense tables start at their initial values and
+        // the first few tens of table-memories decide what the item biases pick up in the tables' place -- measured on config 4's
+        // share, the whole first-epoch deviation of the asynchronous trainer (log-likelihood +7 %, |w_i| +20 % against the oracle)
+        // comes from the first ~1 % of the rows: the sequential stand-in with the tables trained on every 240th row is at +2.1 % /
+        // +6.8 %, with every 8th-15th row for the first 1-2 % of the rows and every 240th afterwards at +0.0 ... +0.2 % / -0.0 ...
+        // +0.5 % (profiles/r03_notes.md section 7).  So those rows run as a launch of their own with a handful of row-loop
+        // workgroups beside the trainer (a row-loop workgroup walks about as many rows per second as the trainer applies steps:
+        // sixteen of them let it see every ~20th row): 500 table-memories of rows (a memory = 1 / (2 beta eta) table steps), at
+        // most 1 / 16 of the epoch.  Measured on config 4's share: first epoch -0.5 ... +0.1 % / |w_i| -2 ... -4 % against the
+        // oracle with 8 or 16 workgroups and 250 or 500 memories alike; it costs that epoch ~1 ms, every other epoch is untouched.
+        int64_t head_units = 0;
+        const int head_rowloops = 16;
+        if (use_segments && feat && !single_group && !feat_frozen && n_producers > 0 && epoch == 0 && cfg->rng_epoch_offset == 0 && u_begin == 0 &&
+            grid - 1 - n_producers > head_rowloops + 4 && !(cfg->debug_flags & 64)) {
+            const double memory = 1.0 / std::max(1e-6, (double)a.reg_b * (double)a.eta);
+            const double frac = std::min(1.0 / 16.0, 500.0 * memory / (double)N);
+            head_units = std::max<int64_t>(1, (int64_t)((double)units * frac));
+            if (head_units > u_end - u_begin) head_units = u_end - u_begin;
+        }
+        if (head_units > 0) {
+            const int saved_direct = a.hot_direct;
+            a.launch_index = (uint32_t)window++;
+            a.pos_begin = u_begin;
+            a.pos_end = u_begin + head_units;
+            a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * head_rowloops ? 1 : 0;
+            launch(a, 1 + n_producers + head_rowloops, stream);
+            a.hot_direct = saved_direct;
+        }
+        for (int64_t p0 = u_begin + head_units; p0 < u_end; p0 += units_per_launch, ++window) {
             a.launch_index = (uint32_t)window;
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;

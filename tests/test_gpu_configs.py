@@ -102,14 +102,16 @@ def test_config4_one_gpu_share_with_features_tracks_sequential_oracle(oracle):
     the reference algorithm itself diverges on these tags.
 
     Two comparisons, both in the engine's order and draws.  (1) The first epoch from the initial weights: the dense tables are
-    trained by ONE sequential stream (the table trainer of sgd_features_kernel) on a sample of the rows -- every ~200th at this
+    trained by ONE sequential stream (the table trainer of sgd_features_kernel) on a sample of the rows -- every ~280th at this
     size (rfm_fit_report.table_steps) -- while the sequential algorithm's tables follow within a few hundred rows of the WHOLE
-    stream; during the first epoch from random weights everything moves fast, the item biases pick up part of what the tables
-    carry in the reference (the two are degenerate: 8 active tags x the mean table row is an item bias), and the epoch ends with
-    the same fit split differently -- stated bounds: log-likelihood 10 %, |w_i| 30 %, factor norms 2 % (measured +7.5 ... +7.7 %,
-    +22.5 ... +23.3 %, 0.0 / -1.2 %: profiles/r03_notes.md).  (2) The second epoch, GPU and oracle both from the GPU's weights
-    after the first: log-likelihood 2 %, every row norm 2 % (measured +0.35 %, <= 0.15 %).  The tables themselves hold mostly
-    gradient noise with a memory of ~170 steps (random tags): only their scale is checked."""
+    stream.  What that costs is decided in the first ~1 % of the rows, while the tables leave their initial values (the item
+    biases pick up what the tables would carry: the two are degenerate, 8 active tags x the mean table row is an item bias), so
+    the fit's opening rows run as a launch of their own in which the trainer sees every ~20th row (rfm_api.hip, "opening"):
+    log-likelihood within 2 %, |w_i| within 5 %, factor norms within 1 % (measured, eight runs: -0.5 ... +0.14 %, -1.95 ...
+    -4.0 % over all opening settings tried, -1.95 ... -2.15 % at the committed one, +0.1 / +0.0 %; without the opening +6.8 ...
+    +7.7 % and +20 ... +23 %: profiles/r03_notes.md section 7).  (2) The second epoch, GPU and oracle both from the GPU's
+    weights after the first: log-likelihood 2 %, every row norm 2 % (measured +0.16 %, <= 0.16 %).  The tables themselves hold
+    mostly gradient noise with a memory of ~170 steps (random tags): only their scale is checked."""
     from rankfm_amd import synthetic
     from rankfm_amd.engine import DeviceSession
     sh = synthetic.make_config_shard("C4", rank=0, world=8)
@@ -134,8 +136,8 @@ def test_config4_one_gpu_share_with_features_tracks_sequential_oracle(oracle):
           % (rep1["log_likelihood"][0] / out1["ll64"][0] - 1.0, r1, rep2["log_likelihood"][0] / out2["ll64"][0] - 1.0, r2, rep2["sgd_kernel_ms"][0],
              geo["table_producers"], geo["table_steps"], 6_250_000 / max(geo["table_steps"], 1)))
     assert geo["table_producers"] >= 1 and geo["table_steps"] > 6_250_000 / 1000      # the trainer keeps up with >= every 1000th row
-    np.testing.assert_allclose(rep1["log_likelihood"], out1["ll64"], rtol=0.10)
-    assert abs(r1["w_i"] - 1.0) <= 0.30 and abs(r1["v_u"] - 1.0) <= 0.02 and abs(r1["v_i"] - 1.0) <= 0.02, r1
+    np.testing.assert_allclose(rep1["log_likelihood"], out1["ll64"], rtol=0.02)
+    assert abs(r1["w_i"] - 1.0) <= 0.05 and abs(r1["v_u"] - 1.0) <= 0.01 and abs(r1["v_i"] - 1.0) <= 0.01, r1
     np.testing.assert_allclose(rep2["log_likelihood"], out2["ll64"], rtol=0.02)
     assert all(abs(r2[k] - 1.0) <= 0.02 for k in ("w_i", "v_u", "v_i")), r2
     for r in (r1, r2):

@@ -160,7 +160,7 @@ def main():
         lr = synthetic.CONFIGS["C4"]["learning_rate"]
         w0p = save_weights(DATA["C4"]["weights"], "c4_init")
         for r in range(a.runs):
-            s = session("C4", max_samples=1, seed=1492, learning_rate=lr, tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune.split(",") if kv})
+            s = session("C4", max_samples=1, seed=1492, learning_rate=lr, debug_flags=int(os.environ.get("LLM_FLAGS", "0")), tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune.split(",") if kv})
             with gpu():
                 rep1 = s.run(epochs=1)
             g1 = s.weights_to_host()
