@@ -845,9 +845,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         // most 1 / 16 of the epoch.  Measured on config 4's share: first epoch -0.5 ... +0.1 % / |w_i| -2 ... -4 % against the
         // oracle with 8 or 16 workgroups and 250 or 500 memories alike; it costs that epoch ~1 ms, every other epoch is untouched.
         int64_t head_units = 0;
-        const int head_rowloops = 16;
+        // (small launches: an eighth of their row-loop workgroups, at least one)
+        const int n_rowloops = grid - 1 - n_producers;
+        const int head_rowloops = std::max(1, std::min(16, n_rowloops / 8));
         if (use_segments && feat && !single_group && !feat_frozen && n_producers > 0 && epoch == 0 && cfg->rng_epoch_offset == 0 && u_begin == 0 &&
-            grid - 1 - n_producers > head_rowloops + 4 && !(cfg->debug_flags & 64)) {
+            n_rowloops >= 2 * head_rowloops && !(cfg->debug_flags & 64)) {
             const double memory = 1.0 / std::max(1e-6, (double)a.reg_b * (double)a.eta);
             const double frac = std::min(1.0 / 16.0, 500.0 * memory / (double)N);
             head_units = std::max<int64_t>(1, (int64_t)((double)units * frac));

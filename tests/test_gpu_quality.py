@@ -42,7 +42,9 @@ def test_feature_model_matches_the_reference():
     """Same bar for a model WITH user and item features (8 + 8 binary tags that carry signal): the reference's numbers are in
     tests/golden/quality_planted_tags.npz (make_quality_tags_golden.py; learning_rate 0.03 -- at its default 0.1 the reference
     itself diverges on dense tags).  The GPU side runs the production feature kernel (sgd_features_kernel: one table trainer
-    workgroup fed by the row loops' staged steps, every other workgroup reading the tables from an LDS copy)."""
+    workgroup fed by step-producer workgroups, every other workgroup reading the tables from an LDS copy; the fit's opening
+    rows as a table-friendly launch of their own).  Measured over 30 runs (tools/feature_quality.py): hit_rate@10 0.4759
+    against the reference's 0.4784, |v_u| +0.6 %, |v_i| -0.2 %, |w_i| -0.9 %."""
     from rankfm_amd import RankFM, evaluation, synthetic
     z = load_golden("quality", "planted_tags")
     cols = list(z["columns"])
@@ -63,11 +65,10 @@ def test_feature_model_matches_the_reference():
             got.append([evaluation.hit_rate(m, test, k=10)] + [np.linalg.norm(getattr(m, k)) for k in ("v_u", "v_i", "w_i", "v_uf", "v_if", "w_if")])
     got, want = np.mean(got, axis=0), ref[:, :7].mean(axis=0)
     print("feature model: got", np.round(got, 4), "reference", np.round(want, 4))
+    # (15 runs: the mean still moves by +-0.5 point from one execution of this test to the next)
     assert abs(got[0] - want[0]) <= 0.015, ("hit_rate@10", got[0], want[0])
-    # |v_u|, |v_i|: measured +2.5 % / +2.0 % -- the replicas' table noise reaches the factors through the feature projections
-    # independently per workgroup instead of coherently (tests/test_gpu_parity.py::test_hogwild_features_statistical_parity)
-    np.testing.assert_allclose(got[1:3], want[1:3], rtol=0.04)
-    np.testing.assert_allclose(got[3], want[3], rtol=0.04)                     # |w_i| (measured -0.4 %)
+    np.testing.assert_allclose(got[1:3], want[1:3], rtol=0.025)                # |v_u|, |v_i|
+    np.testing.assert_allclose(got[3], want[3], rtol=0.025)                    # |w_i|
     # the feature tables hold mostly gradient noise with a memory of ~1/(2 beta eta) rows: scale only
     for k in (4, 5, 6):
         assert 0.5 < got[k] / want[k] < 2.0, (cols[k], got[k], want[k])
