@@ -78,3 +78,34 @@ def test_ll64_is_the_float_accumulators_sum_without_its_rounding(oracle):
     _, out = _fit(oracle, w, pairs, csr, epochs=3)
     assert out["ll64"].shape == (3,) and np.all(out["ll64"] < 0)
     np.testing.assert_allclose(out["ll"], out["ll64"], rtol=2e-6)
+
+
+def _fit_features(oracle, epochs=2, **kw):
+    rng = np.random.default_rng(11)
+    U, I, N, F, P, Q = 50, 30, 1200, 8, 5, 4
+    pairs, csr = synthetic.make_interactions(U, I, N, seed=5)
+    w = synthetic.init_weights(U, I, F, seed=6, n_user_features=P, n_item_features=Q)
+    x_uf = (rng.random((U, P)) < 0.4).astype(np.float32)
+    x_if = (rng.random((I, Q)) < 0.4).astype(np.float32)
+    g = {k: v.copy() for k, v in w.items()}
+    oracle.fit(pairs, np.ones(len(pairs), np.float32), csr.offsets, csr.items, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"],
+               g["v_if"], 0.01, 0.1, 0.03, "constant", 0.25, 1, epochs, perms=None, rng_mode=oracle.RNG_COUNTER, seed=7, membership="binary", **kw)
+    return w, g
+
+
+def test_table_sampling_options_of_the_stand_in(oracle):
+    """`table_every` / `table_head_every` / `table_head_rows` (analysis only: the dense tables trained on every k-th visited row, with
+    another k for the first rows of the call's first epoch -- the sequential stand-in behind the opening launch of feature models,
+    profiles/r03_notes.md section 7): the defaults are the reference bit for bit, a head at k = 1 over a whole one-epoch call is the
+    reference, frozen tables stay at their initial values, and a head changes only what the tables see."""
+    w, ref = _fit_features(oracle)
+    _, a = _fit_features(oracle, table_every=0, table_head_every=0, table_head_rows=0)
+    assert all(np.array_equal(ref[k], a[k]) for k in ref)
+    _, one = _fit_features(oracle, epochs=1)
+    _, b = _fit_features(oracle, epochs=1, table_every=7, table_head_every=1, table_head_rows=10**9)
+    assert all(np.array_equal(one[k], b[k]) for k in one)
+    _, frozen = _fit_features(oracle, table_every=-1)
+    assert all(np.array_equal(frozen[k], w[k]) for k in ("v_uf", "v_if", "w_if")) and not np.array_equal(frozen["v_i"], w["v_i"])
+    _, sparse = _fit_features(oracle, table_every=7)
+    _, head = _fit_features(oracle, table_every=7, table_head_every=1, table_head_rows=300)
+    assert not np.array_equal(sparse["v_uf"], ref["v_uf"]) and not np.array_equal(head["v_uf"], sparse["v_uf"])
