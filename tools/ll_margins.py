@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--procs", type=int, default=min(8, os.cpu_count() or 1))
     ap.add_argument("--damped", action="store_true")
     ap.add_argument("--tune", default="", help="geometry overrides for the config-4 sessions: 'table_producers=6'")
+    ap.add_argument("--debug-flags", type=int, default=0, help="rfm_fit_config.debug_flags of the config-4 sessions (64: no opening launch)")
     a = ap.parse_args()
     configs = a.configs.split(",")
     orc.build()
@@ -160,7 +161,7 @@ def main():
         lr = synthetic.CONFIGS["C4"]["learning_rate"]
         w0p = save_weights(DATA["C4"]["weights"], "c4_init")
         for r in range(a.runs):
-            s = session("C4", max_samples=1, seed=1492, learning_rate=lr, debug_flags=int(os.environ.get("LLM_FLAGS", "0")), tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune.split(",") if kv})
+            s = session("C4", max_samples=1, seed=1492, learning_rate=lr, debug_flags=a.debug_flags, tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune.split(",") if kv})
             with gpu():
                 rep1 = s.run(epochs=1)
             g1 = s.weights_to_host()
