@@ -102,6 +102,55 @@ class SharedTables:
         scale[a:a + self._sizes["w_i"]] = torch.clamp(float(bias_damping) / n, min=1.0 / world_size, max=1.0)
         self.merge_scale = scale if world_size > 1 else None
 
+    # The curvature rule (the default from round 3's end on).  An item row that a rank steps n times in an exchange window moves
+    # about (1 - rho^n) of the way to where that rank's data would take it, rho = 1 - kappa, kappa = eta x (curvature of the loss
+    # along the row) -- for a factor row ~ eta x c x mean |v_u|^2 (the logistic term's second derivative is sigma' <= 1/4 times the
+    # squared projection of v_u), for a bias eta x c_w.  The same steps taken one rank after the other would move it
+    # (1 - rho^(sum n_r)): the scale of the SUMMED deltas is
+    #     s_i = (1 - rho^N_i) / sum_r (1 - rho^n_ri),        N_i = sum_r n_ri
+    # -- 1 while the steps are few (the deltas add up), 1 / ranks once every rank has taken many (they all say the same thing) --
+    # and it follows the model: |v_u|^2 grows by an order of magnitude over the first epochs, so summing is right early and
+    # averaging later, which no constant M of the clamp rule (set_merge_damping) can say.  CPU emulation, 8 shards trained by the
+    # sequential oracle (tools/merge_emulation.py, profiles/r03_notes.md section 5): hit_rate@10 against sequential training
+    # MovieLens-shaped 0.943 / 0.932 (sequential 0.928 / 0.935 at learning rates 0.1 / 0.03; clamp rule 0.928 / 0.914),
+    # Zipf(1) items 0.783 / 0.582 (0.790 / 0.606; clamp rule 0.714 / 0.512).  c = 0.1 for the factors (0.03 ... 0.12 within a
+    # point of each other), c_w = 0.3 for the biases (0.25 holds everywhere, 0.12 lets them run away at learning rate 0.1).
+    CURVATURE_FACTORS, CURVATURE_BIASES = 0.1, 0.3
+
+    def set_merge_curvature(self, local_item_counts, world_size, learning_rate=0.1, c_factors=None, c_biases=None):
+        """arm the curvature rule: `local_item_counts` [I] = this rank's updates of every item per exchange window.  The scale
+        itself is computed by refresh_merge_scale before every exchange (it needs the ranks' current mean |v_u|^2)."""
+        self._n_local = torch.as_tensor(np.asarray(local_item_counts, dtype=np.float64), dtype=torch.float64, device=self.flat.device)
+        self._curvature = (float(learning_rate), float(self.CURVATURE_FACTORS if c_factors is None else c_factors),
+                           float(self.CURVATURE_BIASES if c_biases is None else c_biases))
+        self._world = int(world_size)
+        self.merge_scale = torch.full_like(self.flat, 1.0 / world_size) if world_size > 1 else None      # (feature tables: the average)
+
+    def refresh_merge_scale(self, sum_vu2, n_users, group=None):
+        """the curvature rule's scale for the coming exchange: `sum_vu2` / `n_users` = this rank's sum of |v_u|^2 and user count
+        (two small all-reduces: the mean over all ranks, and the per-item terms)"""
+        if getattr(self, "_curvature", None) is None or self.merge_scale is None:
+            return
+        lr, c_v, c_w = self._curvature
+        dev = self.flat.device
+        stat = torch.tensor([float(sum_vu2), float(n_users)], dtype=torch.float64, device=dev)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(stat, op=dist.ReduceOp.SUM, group=group)
+        if float(stat[1]) <= 0.0:
+            return                       # (nobody reported its users: the scale stays what it was -- the average, initially)
+        mean_vu2 = float(stat[0] / stat[1])
+        log_rho = curvature_log_rho(lr, c_v, c_w, mean_vu2)
+        terms = curvature_terms(self._n_local, log_rho)                                             # [3, I]
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(terms, op=dist.ReduceOp.SUM, group=group)
+        sv, sb = curvature_scales(terms, log_rho, self._world)
+        F = self._shapes["v_i"][1]
+        a = self._starts["v_i"]
+        self.merge_scale[a:a + self._sizes["v_i"]] = sv.to(torch.float32).repeat_interleave(F)
+        a = self._starts["w_i"]
+        self.merge_scale[a:a + self._sizes["w_i"]] = sb.to(torch.float32)
+        self.last_curvature = dict(mean_vu2=mean_vu2, kappa_factors=lr * c_v * mean_vu2, kappa_biases=lr * c_w)
+
     def begin_epoch(self):
         self.start.copy_(self.flat)
 
@@ -138,6 +187,29 @@ class SharedTables:
         return self.flat.numel() * 4
 
 
+def curvature_log_rho(learning_rate, c_factors, c_biases, mean_vu2):
+    """log rho of the curvature rule (SharedTables.set_merge_curvature) for the factor rows and for the biases"""
+    return (float(np.log1p(-min(learning_rate * c_factors * mean_vu2, 0.5))), float(np.log1p(-min(learning_rate * c_biases, 0.5))))
+
+
+def curvature_terms(n_local, log_rho):
+    """what ONE rank contributes to the curvature rule: [1 - rho_v^n | 1 - rho_w^n | n] per item (float64 [3, I]); the ranks' terms
+    are summed (one all-reduce) before curvature_scales"""
+    n = torch.as_tensor(n_local, dtype=torch.float64)
+    return torch.stack([-torch.expm1(log_rho[0] * n), -torch.expm1(log_rho[1] * n), n])
+
+
+def curvature_scales(terms_sum, log_rho, world_size):
+    """(scale of the summed factor-row deltas, scale of the summed bias deltas) per item:  (1 - rho^N) / sum_r (1 - rho^n_r),
+    clipped to [1 / ranks, 1]; 1 for an item nobody stepped"""
+    N, lo = terms_sum[2], 1.0 / world_size
+    out = []
+    for k in (0, 1):
+        s = torch.where(terms_sum[k] > 0, -torch.expm1(log_rho[k] * N) / torch.clamp(terms_sum[k], min=1e-300), torch.ones_like(N))
+        out.append(s.clamp(lo, 1.0))
+    return out[0], out[1]
+
+
 def broadcast_from_rank0(tensors, group=None):
     """make the replicated tables identical on every rank before training"""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -152,9 +224,18 @@ class ShardedTrainer:
     `DeviceSession.run` (see make_device_trainer), in the CPU tests it is any stand-in with the same contract.
     """
 
-    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1):
+    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None):
         self.shared, self.epoch_fn, self.group, self.average = shared, epoch_fn, group, average
         self.syncs_per_epoch = syncs_per_epoch
+        # () -> (sum over this rank's users of |v_u|^2, number of users): what the curvature rule of the merge needs before
+        # every exchange (SharedTables.refresh_merge_scale); None = the rank has no users
+        self.user_norms_fn = user_norms_fn
+
+    def _exchange(self):
+        if getattr(self.shared, "_curvature", None) is not None and not self.average:
+            s, n = self.user_norms_fn() if self.user_norms_fn is not None else (0.0, 0)
+            self.shared.refresh_merge_scale(s, n, self.group)
+        self.shared.all_reduce_deltas(self.group, self.average)
 
     def _local(self, epoch, **kw):
         """one local slice, then agree on its outcome BEFORE the next collective: a rank whose slice failed (saturated user,
@@ -178,13 +259,13 @@ class ShardedTrainer:
         if self.syncs_per_epoch <= 1:
             self.shared.begin_epoch()
             out = self._local(epoch)
-            self.shared.all_reduce_deltas(self.group, self.average)
+            self._exchange()
             return out
         total = None
         for k in range(self.syncs_per_epoch):
             self.shared.begin_epoch()
             out = self._local(epoch, part=(k, self.syncs_per_epoch))
-            self.shared.all_reduce_deltas(self.group, self.average)
+            self._exchange()
             if total is None:
                 total = {key: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for key, v in out.items()}
             else:
@@ -195,13 +276,18 @@ class ShardedTrainer:
 
 
 def agree_on_merge_damping(shared, shard, group=None, merge_damping=None, syncs_per_epoch=1, learning_rate=0.1):
-    """the damped merge needs every item's update count over ALL ranks per exchange window: one all-reduce of the ranks' item
-    histograms, then SharedTables.set_merge_damping (a no-op without a process group / on one rank)"""
+    """arm the damped merge (a no-op without a process group / on one rank).  merge_damping None: the curvature rule
+    (SharedTables.set_merge_curvature: every rank keeps its OWN item histogram per exchange window, the scale is refreshed
+    before every exchange by ShardedTrainer).  A number M: the clamp rule min(1, M / n_i) of rounds 1-3, which needs every item's
+    update count over ALL ranks: one all-reduce of the ranks' item histograms, then SharedTables.set_merge_damping."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     device = shared.flat.device
     counts = torch.bincount(torch.as_tensor(np.asarray(shard["interactions"])[:, 1].astype(np.int64)),
                             minlength=shared.views["w_i"].shape[0]).to(device=device, dtype=torch.float32)
+    if merge_damping is None:
+        shared.set_merge_curvature(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), learning_rate=learning_rate)
+        return
     dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     # the damping counts updates per exchange window
     shared.set_merge_damping(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), merge_damping,
@@ -232,7 +318,11 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
     def epoch_fn(_views, epoch, part=None):
         return sess.run(epochs=1, epoch_begin=epoch, part=part)
 
-    return ShardedTrainer(shared, epoch_fn, group=group, average=average, syncs_per_epoch=syncs_per_epoch), sess
+    def user_norms():
+        v = sess.weights["v_u"]
+        return float((v.double() ** 2).sum().item()), int(v.shape[0])
+
+    return ShardedTrainer(shared, epoch_fn, group=group, average=average, syncs_per_epoch=syncs_per_epoch, user_norms_fn=user_norms), sess
 
 
 def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,

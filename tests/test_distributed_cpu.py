@@ -160,7 +160,8 @@ def _fit_worker(rank, world, port, out_dir):
                            t["w_if"], shard["v_u"], t["v_i"], t["v_uf"], t["v_if"], hyper["alpha"], hyper["beta"], hyper["learning_rate"],
                            hyper["learning_schedule"], hyper["learning_exponent"], hyper["max_samples"], 1, perms=None,
                            rng_mode=orc.RNG_COUNTER, seed=5 + dist.get_rank(), epoch_begin=epoch, membership="binary")
-        return ShardedTrainer(shared, epoch_fn), (lambda: shard["v_u"])
+        return (ShardedTrainer(shared, epoch_fn, user_norms_fn=lambda: (float((shard["v_u"].astype(np.float64) ** 2).sum()), len(shard["v_u"]))),
+                (lambda: shard["v_u"]))
 
     m = RankFM(factors=F)
     np.random.seed(3)
@@ -269,7 +270,7 @@ def test_config_shards_are_the_interaction_balanced_user_split(monkeypatch):
         assert all(np.array_equal(sh["weights"][k], whole["weights"][k]) for k in SHARED_NAMES)
 
 
-def _merge_emulation(oracle, world, epochs, lr, U=3000, I=2000, F=16):
+def _merge_emulation(oracle, world, epochs, lr, U=3000, I=2000, F=16, rule="clamp"):
     """`world` user shards trained by the oracle from the same epoch-start tables and merged with SharedTables' scale after
     every epoch -- what ShardedTrainer does across ranks, in one process -- next to sequential training of the whole data."""
     from rankfm_amd._rankfm import UserItemsCSR
@@ -301,8 +302,16 @@ def _merge_emulation(oracle, world, epochs, lr, U=3000, I=2000, F=16):
               for r in range(world)]
     shared = SharedTables({k: w[k].copy() for k in SHARED_NAMES}, torch.device("cpu"))
     shared.set_merge_damping(np.bincount(pairs[:, 1], minlength=I), world, learning_rate=lr)
+    n_rank = [np.bincount(s["interactions"][:, 1], minlength=I) for s in shards]
     ll = np.zeros(epochs)
     for e in range(epochs):
+        if rule == "curvature":       # what ShardedTrainer._exchange does before every exchange, the ranks' terms summed by hand
+            from rankfm_amd.distributed import curvature_log_rho, curvature_scales, curvature_terms
+            mean_vu2 = float(np.mean(np.concatenate([np.sum(s["v_u"].astype(np.float64) ** 2, axis=1) for s in shards])))
+            log_rho = curvature_log_rho(lr, SharedTables.CURVATURE_FACTORS, SharedTables.CURVATURE_BIASES, mean_vu2)
+            sv, sb = curvature_scales(sum(curvature_terms(n, log_rho) for n in n_rank), log_rho, world)
+            a = shared._starts["v_i"]; shared.merge_scale[a:a + shared._sizes["v_i"]] = sv.to(torch.float32).repeat_interleave(F)
+            a = shared._starts["w_i"]; shared.merge_scale[a:a + shared._sizes["w_i"]] = sb.to(torch.float32)
         start, total = shared.flat.clone(), torch.zeros_like(shared.flat)
         for k, s in enumerate(shards):
             shared.flat.copy_(start)
@@ -328,3 +337,27 @@ def test_eight_user_shards_with_the_damped_merge_track_sequential_training(oracl
     assert abs(r["hit"] - r["hit_seq"]) <= 0.015, r
     assert r["ll"][-1] > r["ll"][0] and abs(r["ll"][-1] / r["ll_seq"][-1] - 1.0) <= 0.10, r
     assert 0.8 <= r["w_i"] <= 1.2 and 0.8 <= r["v_i"] <= 1.1, r
+
+
+@pytest.mark.parametrize("lr, epochs", [(0.1, 10), (0.03, 20)])
+def test_eight_user_shards_with_the_curvature_merge_track_sequential_training(oracle, lr, epochs):
+    """the same emulation with the merge rule fit_distributed uses by default since the end of round 3 (SharedTables.set_merge_curvature:
+    the scale of the summed deltas follows the model's mean |v_u|^2, so the ranks' deltas are summed early and averaged late)."""
+    r = _merge_emulation(oracle, 8, epochs, lr, rule="curvature")
+    print("curvature merge, lr %g: hit_rate@10 %.4f (sequential %.4f)  last-epoch LL / sequential - 1 %+.3f  |w_i| %.3f |v_i| %.3f"
+          % (lr, r["hit"], r["hit_seq"], r["ll"][-1] / r["ll_seq"][-1] - 1.0, r["w_i"], r["v_i"]))
+    assert abs(r["hit"] - r["hit_seq"]) <= 0.015, r
+    assert r["ll"][-1] > r["ll"][0] and abs(r["ll"][-1] / r["ll_seq"][-1] - 1.0) <= 0.10, r
+
+
+def test_curvature_rule_limits():
+    """few steps: the ranks' deltas add up (scale 1); many steps on every rank: they all say the same thing (scale 1 / ranks); an item
+    only ONE rank steps keeps scale 1 however often; an item nobody steps: 1"""
+    from rankfm_amd.distributed import curvature_log_rho, curvature_scales, curvature_terms
+    log_rho = curvature_log_rho(0.1, 0.1, 0.3, 2.0)
+    n = [np.array([1.0, 5000.0, 5000.0, 0.0]), np.array([1.0, 5000.0, 0.0, 0.0]), np.array([0.0, 5000.0, 0.0, 0.0]), np.array([1.0, 5000.0, 0.0, 0.0])]
+    sv, sb = curvature_scales(sum(curvature_terms(x, log_rho) for x in n), log_rho, 4)
+    np.testing.assert_allclose(sv.numpy(), [1.0, 0.25, 1.0, 1.0], atol=0.03)
+    np.testing.assert_allclose(sb.numpy(), [1.0, 0.25, 1.0, 1.0], atol=0.05)
+    mid = curvature_scales(sum(curvature_terms(np.array([40.0]), log_rho) for _ in range(4)), log_rho, 4)[0].item()
+    assert 0.3 < mid < 0.9            # 40 steps per rank at kappa = 0.02: between the sum and the average

@@ -3,7 +3,8 @@ ranks of rankfm_amd/distributed.py do (SharedTables.merge_scale), against sequen
 MovieLens-1M-shaped planted problem.
     python tools/merge_emulation.py [epochs] [learning_rate] [zipf]
 `zipf`: a larger problem (40,000 x 8,000, 1.8 M rows) whose item frequencies follow the Zipf(1) of BASELINE config 4 instead of the
-MovieLens-shaped skew.  Edit the (world, M factors, M biases) list at the bottom for other settings.  Numbers in profiles/r02_notes.md /
+MovieLens-shaped skew.  Fourth argument: settings "M:MW,..." in units of the clamp rule's default M, or "auto:C:CW[:ranks]" = the
+curvature rule of SharedTables.set_merge_curvature with constants C (factors) and CW (biases).  Numbers in profiles/r02_notes.md /
 r03_notes.md.
 (test / analysis infrastructure: uses oracle/)"""
 import os
@@ -56,9 +57,15 @@ counts = np.bincount(pairs[:, 1], minlength=I)
 print("item frequency: top item %.2f %% of the rows, top 1 %% of the items %.1f %%" % (100.0 * counts.max() / N, 100.0 * np.sort(counts)[::-1][:max(I // 100, 1)].sum() / N))
 RULE = (3.2 / LR, 3.2 / LR / 4.0)          # the committed rule of SharedTables.set_merge_damping at >= 4 ranks
 SETTINGS = ((8,) + RULE, (8, 2 * RULE[0], RULE[1]), (8, RULE[0], RULE[0]), (8, 0.5 * RULE[0], 0.5 * RULE[1]))
-if len(sys.argv) > 4:                      # "M:MW,M:MW,..." in units of the committed rule's M
-    SETTINGS = tuple((8, float(x.split(":")[0]) * RULE[0], float(x.split(":")[1]) * RULE[0]) for x in sys.argv[4].split(","))
-for world, M, MW in SETTINGS:
+if len(sys.argv) > 4:                      # "M:MW,M:MW,..." in units of the committed rule's M; "auto:C:CW" = the curvature rule
+    SETTINGS = tuple((int(x.split(":")[3]) if x.count(":") >= 3 else 8, x) if x.startswith("auto") else (8, float(x.split(":")[0]) * RULE[0], float(x.split(":")[1]) * RULE[0])
+                     for x in sys.argv[4].split(","))
+for setting in SETTINGS:
+    world = setting[0]
+    auto = isinstance(setting[1], str)
+    M, MW = (RULE if auto else setting[1:])
+    if auto:
+        c_v, c_w = float(setting[1].split(":")[1]), float(setting[1].split(":")[2])
     bounds = shard_boundaries(csr.offsets, world)
     shards = [take_user_shard(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), w["v_u"].copy(), bounds[r], bounds[r + 1]) for r in range(world)]
     ref = SharedTables({k: w[k].copy() for k in SHARED_NAMES}, torch.device("cpu"))
@@ -67,7 +74,24 @@ for world, M, MW in SETTINGS:
     nn = torch.as_tensor(counts.astype(np.float32))
     ref.merge_scale[a:a + ref._sizes["w_i"]] = torch.clamp(MW / torch.clamp(nn, min=1.0), min=1.0 / world, max=1.0)
     ll = np.zeros(E)
+    n_rank = np.stack([np.bincount(s["interactions"][:, 1], minlength=I) for s in shards]).astype(np.float64) if auto else None     # [world, I]
     for e in range(E):
+        if auto:
+            # curvature rule: an item row that rank r steps n_r times moves by (1 - rho^n_r) of the way to its optimum, rho = 1 - kappa,
+            # kappa = eta x curvature ~ eta x c x mean |v_u|^2 (biases: eta x c_w); applied one after the other the ranks' steps
+            # would move it (1 - rho^sum n_r): scale of the SUMMED deltas = (1 - rho^N) / sum_r (1 - rho^n_r)   (1 for few steps, 1 / ranks for many)
+            mean_vu2 = float(np.mean([np.mean(np.sum(s["v_u"].astype(np.float64) ** 2, axis=1)) for s in shards]))
+            def sat(kappa):
+                lr_ = np.log1p(-min(kappa, 0.5))
+                num = -np.expm1(lr_ * n_rank.sum(axis=0))
+                den = (-np.expm1(lr_ * n_rank)).sum(axis=0)
+                return np.where(den > 0, num / np.maximum(den, 1e-30), 1.0)
+            sv, sb = sat(LR * c_v * mean_vu2), sat(LR * c_w)
+            a_ = ref._starts["v_i"]; ref.merge_scale[a_:a_ + ref._sizes["v_i"]] = torch.as_tensor(np.repeat(sv, F).astype(np.float32))
+            a_ = ref._starts["w_i"]; ref.merge_scale[a_:a_ + ref._sizes["w_i"]] = torch.as_tensor(sb.astype(np.float32))
+            if e in (0, E - 1):
+                print("   epoch %d: mean |v_u|^2 %.3f  kappa_v %.4f (M ~ %.0f)  scale of the busiest / median item %.3f / %.3f" % (
+                    e, mean_vu2, LR * c_v * mean_vu2, 1.0 / (LR * c_v * mean_vu2), sv[np.argmax(counts)], np.median(sv)), flush=True)
         start = ref.flat.clone(); total = torch.zeros_like(start)
         for k in range(world):
             ref.flat.copy_(start)
@@ -82,4 +106,4 @@ for world, M, MW in SETTINGS:
     v_u = np.concatenate([s["v_u"] for s in shards])
     v_i, w_i = ref.views["v_i"].numpy(), ref.views["w_i"].numpy()
     nr = [float(np.linalg.norm(a) / np.linalg.norm(b) - 1) for a, b in ((v_u, o["v_u"]), (v_i, o["v_i"]), (w_i, o["w_i"]))]
-    print("world %d M %g MW " % (world, M) + str(MW) + ": hit_rate@10 %.4f  LL/seq-1 %s  norms-1 %s" % (hit_rate(v_u, v_i, w_i), np.round(ll / ll_seq - 1, 3), np.round(nr, 3)), flush=True)
+    print("world %d %s" % (world, setting[1]) if auto else "world %d M %g MW " % (world, M) + str(MW), ": hit_rate@10 %.4f  LL/seq-1 %s  norms-1 %s" % (hit_rate(v_u, v_i, w_i), np.round(ll / ll_seq - 1, 3), np.round(nr, 3)), flush=True)
