@@ -335,6 +335,10 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     deltas once per epoch (ShardedTrainer).  At the end the user factors and the item lists are all-gathered, so every rank returns the
     complete fitted model with the reference's attribute layout.  With world size 1 this is `model.fit(...)` on the resident-session path.
 
+    `merge_damping`: None = the curvature rule for scaling the summed deltas (SharedTables.set_merge_curvature: follows the model's
+    mean |v_u|^2, no constant to choose); a number M = the clamp rule min(1, M / n_i) of earlier rounds.  `syncs_per_epoch` > 1
+    exchanges the deltas several times per epoch (smaller windows: every row's steps per exchange shrink).
+
     `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
     CPU tests; `finish()` must return the shard's trained v_u as a numpy array.
     """
