@@ -23,22 +23,29 @@ orc.build()
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 LR = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
 ZIPF = len(sys.argv) > 3 and sys.argv[3] == "zipf"
+TAGS = 8 if len(sys.argv) > 3 and sys.argv[3] == "tags" else 0     # MovieLens-shaped with 8 + 8 binary tags that carry signal (feature tables: averaged)
 if ZIPF:
     U, I, F = 40000, 8000, 20
     d = synthetic.make_planted_large(U, I, seed=0, mean_degree=60.0, pop_weight=1.0)
 else:
     U, I, F = 6040, 3706, 20
-    d = synthetic.make_planted(seed=0)
+    d = synthetic.make_planted(seed=0, n_tags=TAGS)
 pairs, test = d["train"], d["test"]
+X_UF = d["user_tags"].astype(np.float32) if TAGS else np.zeros((U, 1), np.float32)
+X_IF = d["item_tags"].astype(np.float32) if TAGS else np.zeros((I, 1), np.float32)
 N = len(pairs)
 csr = UserItemsCSR.from_pairs(pairs[:, 0], pairs[:, 1], U)
-w = synthetic.init_weights(U, I, F, seed=3)
+w = synthetic.init_weights(U, I, F, seed=3, n_user_features=TAGS or 1, n_item_features=TAGS or 1) if TAGS else synthetic.init_weights(U, I, F, seed=3)
 sw = np.ones(N, np.float32)
-z_i = np.zeros((I, 1), np.float32)
+z_i = X_IF
 test_users = np.unique(test[:, 0])
 tcsr = UserItemsCSR.from_pairs(test[:, 0], test[:, 1], U)
-def hit_rate(v_u, v_i, w_i, k=10):
+def hit_rate(v_u, v_i, w_i, k=10, tabs=None):
     hits = 0
+    if tabs is not None:        # (w_if, v_uf, v_if): the effective rows of a model with features (rankfm/_rankfm.pyx:48-89)
+        v_u = v_u + X_UF @ tabs[1]
+        w_i = w_i + X_IF @ tabs[0]
+        v_i = v_i + X_IF @ tabs[2]
     for u0 in range(0, len(test_users), 512):
         us = test_users[u0:u0 + 512]
         S = v_u[us] @ v_i.T + w_i
@@ -49,10 +56,10 @@ def hit_rate(v_u, v_i, w_i, k=10):
             hits += bool(np.intersect1d(top[r], tcsr.items[tcsr.offsets[u]:tcsr.offsets[u + 1]]).size)
     return hits / len(test_users)
 o = {k: v.copy() for k, v in w.items()}
-out = orc.fit(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), z_i, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"],
+out = orc.fit(pairs, sw, csr.offsets, csr.items, X_UF, z_i, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"], o["v_if"],
               0.01, 0.1, LR, "constant", 0.25, 1, E, perms=None, rng_mode=orc.RNG_COUNTER, seed=1, membership="binary")
 ll_seq = out["ll"]
-print("sequential: hit_rate@10 %.4f" % hit_rate(o["v_u"], o["v_i"], o["w_i"]), "LL/N", np.round(ll_seq / N, 4), flush=True)
+print("sequential: hit_rate@10 %.4f" % hit_rate(o["v_u"], o["v_i"], o["w_i"], tabs=(o["w_if"], o["v_uf"], o["v_if"]) if TAGS else None), "LL/N", np.round(ll_seq / N, 4), flush=True)
 counts = np.bincount(pairs[:, 1], minlength=I)
 print("item frequency: top item %.2f %% of the rows, top 1 %% of the items %.1f %%" % (100.0 * counts.max() / N, 100.0 * np.sort(counts)[::-1][:max(I // 100, 1)].sum() / N))
 RULE = (3.2 / LR, 3.2 / LR / 4.0)          # the committed rule of SharedTables.set_merge_damping at >= 4 ranks
@@ -67,7 +74,7 @@ for setting in SETTINGS:
     if auto:
         c_v, c_w = float(setting[1].split(":")[1]), float(setting[1].split(":")[2])
     bounds = shard_boundaries(csr.offsets, world)
-    shards = [take_user_shard(pairs, sw, csr.offsets, csr.items, np.zeros((U, 1), np.float32), w["v_u"].copy(), bounds[r], bounds[r + 1]) for r in range(world)]
+    shards = [take_user_shard(pairs, sw, csr.offsets, csr.items, X_UF, w["v_u"].copy(), bounds[r], bounds[r + 1]) for r in range(world)]
     ref = SharedTables({k: w[k].copy() for k in SHARED_NAMES}, torch.device("cpu"))
     ref.set_merge_damping(counts, world, damping=M)
     a = ref._starts["w_i"]
@@ -97,7 +104,7 @@ for setting in SETTINGS:
             ref.flat.copy_(start)
             t = {n: ref.views[n].numpy() for n in SHARED_NAMES}
             s = shards[k]
-            r = orc.fit(s["interactions"], s["sample_weight"], s["csr_offsets"], s["csr_items"], np.zeros((len(s["v_u"]), 1), np.float32), z_i,
+            r = orc.fit(s["interactions"], s["sample_weight"], s["csr_offsets"], s["csr_items"], s["x_uf"], z_i,
                         t["w_i"], t["w_if"], s["v_u"], t["v_i"], t["v_uf"], t["v_if"], 0.01, 0.1, LR, "constant", 0.25, 1, 1, perms=None,
                         rng_mode=orc.RNG_COUNTER, seed=100 + k, epoch_begin=e, membership="binary")
             ll[e] += r["ll"][0]
@@ -106,4 +113,4 @@ for setting in SETTINGS:
     v_u = np.concatenate([s["v_u"] for s in shards])
     v_i, w_i = ref.views["v_i"].numpy(), ref.views["w_i"].numpy()
     nr = [float(np.linalg.norm(a) / np.linalg.norm(b) - 1) for a, b in ((v_u, o["v_u"]), (v_i, o["v_i"]), (w_i, o["w_i"]))]
-    print("world %d %s" % (world, setting[1]) if auto else "world %d M %g MW " % (world, M) + str(MW), ": hit_rate@10 %.4f  LL/seq-1 %s  norms-1 %s" % (hit_rate(v_u, v_i, w_i), np.round(ll / ll_seq - 1, 3), np.round(nr, 3)), flush=True)
+    print("world %d %s" % (world, setting[1]) if auto else "world %d M %g MW " % (world, M) + str(MW), ": hit_rate@10 %.4f  LL/seq-1 %s  norms-1 %s" % (hit_rate(v_u, v_i, w_i, tabs=tuple(ref.views[n].numpy() for n in ("w_if", "v_uf", "v_if")) if TAGS else None), np.round(ll / ll_seq - 1, 3), np.round(nr, 3)), flush=True)
