@@ -126,12 +126,15 @@ class SharedTables:
         self._world = int(world_size)
         self.merge_scale = torch.full_like(self.flat, 1.0 / world_size) if world_size > 1 else None      # (feature tables: the average)
 
-    def refresh_merge_scale(self, sum_vu2, n_users, group=None):
+    def refresh_merge_scale(self, sum_vu2, n_users, group=None, eta=None):
         """the curvature rule's scale for the coming exchange: `sum_vu2` / `n_users` = this rank's sum of |v_u|^2 and user count
-        (two small all-reduces: the mean over all ranks, and the per-item terms)"""
+        (two small all-reduces: the mean over all ranks, and the per-item terms); `eta` = the learning rate of the epoch just
+        trained when it differs from the one the rule was armed with ('invscaling' schedule)"""
         if getattr(self, "_curvature", None) is None or self.merge_scale is None:
             return
         lr, c_v, c_w = self._curvature
+        if eta is not None:
+            lr = float(eta)
         dev = self.flat.device
         stat = torch.tensor([float(sum_vu2), float(n_users)], dtype=torch.float64, device=dev)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -224,17 +227,19 @@ class ShardedTrainer:
     `DeviceSession.run` (see make_device_trainer), in the CPU tests it is any stand-in with the same contract.
     """
 
-    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None):
+    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None):
         self.shared, self.epoch_fn, self.group, self.average = shared, epoch_fn, group, average
         self.syncs_per_epoch = syncs_per_epoch
+        self.eta_fn = eta_fn             # epoch -> learning rate of that epoch (None: the constant the merge rule was armed with)
         # () -> (sum over this rank's users of |v_u|^2, number of users): what the curvature rule of the merge needs before
         # every exchange (SharedTables.refresh_merge_scale); None = the rank has no users
         self.user_norms_fn = user_norms_fn
 
-    def _exchange(self):
+    def _exchange(self, epoch=None):
         if getattr(self.shared, "_curvature", None) is not None and not self.average:
             s, n = self.user_norms_fn() if self.user_norms_fn is not None else (0.0, 0)
-            self.shared.refresh_merge_scale(s, n, self.group)
+            eta = self.eta_fn(epoch) if (self.eta_fn is not None and epoch is not None) else None
+            self.shared.refresh_merge_scale(s, n, self.group, eta=eta)
         self.shared.all_reduce_deltas(self.group, self.average)
 
     def _local(self, epoch, **kw):
@@ -259,13 +264,13 @@ class ShardedTrainer:
         if self.syncs_per_epoch <= 1:
             self.shared.begin_epoch()
             out = self._local(epoch)
-            self._exchange()
+            self._exchange(epoch)
             return out
         total = None
         for k in range(self.syncs_per_epoch):
             self.shared.begin_epoch()
             out = self._local(epoch, part=(k, self.syncs_per_epoch))
-            self._exchange()
+            self._exchange(epoch)
             if total is None:
                 total = {key: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for key, v in out.items()}
             else:
@@ -322,7 +327,14 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
         v = sess.weights["v_u"]
         return float((v.double() ** 2).sum().item()), int(v.shape[0])
 
-    return ShardedTrainer(shared, epoch_fn, group=group, average=average, syncs_per_epoch=syncs_per_epoch, user_norms_fn=user_norms), sess
+    def eta_of(epoch):          # rankfm/_rankfm.pyx:220-223
+        lr = float(hyper.get("learning_rate", 0.1))
+        if hyper.get("learning_schedule", "constant") == "invscaling":
+            return lr / float(epoch + 1) ** float(hyper.get("learning_exponent", 0.25))
+        return lr
+
+    return ShardedTrainer(shared, epoch_fn, group=group, average=average, syncs_per_epoch=syncs_per_epoch, user_norms_fn=user_norms,
+                          eta_fn=eta_of), sess
 
 
 def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,
