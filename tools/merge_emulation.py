@@ -23,6 +23,7 @@ orc.build()
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 LR = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
 ZIPF = len(sys.argv) > 3 and sys.argv[3] == "zipf"
+SYNCS = int(sys.argv[5]) if len(sys.argv) > 5 else 1     # exchanges per epoch (every rank trains every SYNCS-th row of its shard between two of them)
 TAGS = 8 if len(sys.argv) > 3 and sys.argv[3] == "tags" else 0     # MovieLens-shaped with 8 + 8 binary tags that carry signal (feature tables: averaged)
 if ZIPF:
     U, I, F = 40000, 8000, 20
@@ -81,8 +82,9 @@ for setting in SETTINGS:
     nn = torch.as_tensor(counts.astype(np.float32))
     ref.merge_scale[a:a + ref._sizes["w_i"]] = torch.clamp(MW / torch.clamp(nn, min=1.0), min=1.0 / world, max=1.0)
     ll = np.zeros(E)
-    n_rank = np.stack([np.bincount(s["interactions"][:, 1], minlength=I) for s in shards]).astype(np.float64) if auto else None     # [world, I]
+    n_rank = np.stack([np.bincount(s["interactions"][:, 1], minlength=I) for s in shards]).astype(np.float64) / SYNCS if auto else None     # [world, I]
     for e in range(E):
+      for part in range(SYNCS):
         if auto:
             # curvature rule: an item row that rank r steps n_r times moves by (1 - rho^n_r) of the way to its optimum, rho = 1 - kappa,
             # kappa = eta x curvature ~ eta x c x mean |v_u|^2 (biases: eta x c_w); applied one after the other the ranks' steps
@@ -96,7 +98,7 @@ for setting in SETTINGS:
             sv, sb = sat(LR * c_v * mean_vu2), sat(LR * c_w)
             a_ = ref._starts["v_i"]; ref.merge_scale[a_:a_ + ref._sizes["v_i"]] = torch.as_tensor(np.repeat(sv, F).astype(np.float32))
             a_ = ref._starts["w_i"]; ref.merge_scale[a_:a_ + ref._sizes["w_i"]] = torch.as_tensor(sb.astype(np.float32))
-            if e in (0, E - 1):
+            if e in (0, E - 1) and part == 0:
                 print("   epoch %d: mean |v_u|^2 %.3f  kappa_v %.4f (M ~ %.0f)  scale of the busiest / median item %.3f / %.3f" % (
                     e, mean_vu2, LR * c_v * mean_vu2, 1.0 / (LR * c_v * mean_vu2), sv[np.argmax(counts)], np.median(sv)), flush=True)
         start = ref.flat.clone(); total = torch.zeros_like(start)
@@ -104,7 +106,7 @@ for setting in SETTINGS:
             ref.flat.copy_(start)
             t = {n: ref.views[n].numpy() for n in SHARED_NAMES}
             s = shards[k]
-            r = orc.fit(s["interactions"], s["sample_weight"], s["csr_offsets"], s["csr_items"], s["x_uf"], z_i,
+            r = orc.fit(np.ascontiguousarray(s["interactions"][part::SYNCS]), np.ascontiguousarray(s["sample_weight"][part::SYNCS]), s["csr_offsets"], s["csr_items"], s["x_uf"], z_i,
                         t["w_i"], t["w_if"], s["v_u"], t["v_i"], t["v_uf"], t["v_if"], 0.01, 0.1, LR, "constant", 0.25, 1, 1, perms=None,
                         rng_mode=orc.RNG_COUNTER, seed=100 + k, epoch_begin=e, membership="binary")
             ll[e] += r["ll"][0]
