@@ -306,6 +306,7 @@ def main():
                        "n_users_total": u_local * world, "n_interactions_total": n_job, "parallelism": "user-shard dp%d" % world,
                        "rccl_ranks_seen": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
                        "collective_backend": dist.get_backend() if world > 1 else None,
+                       "merge_rule": ("curvature rule (SharedTables.set_merge_curvature), %d exchange(s) per epoch" % args.syncs_per_epoch) if world > 1 else None,
                        "sgd_launches_per_epoch": launches, "waves_per_launch": rep["waves_per_launch"],
                        "mean_draws_per_update": mean_draws, "final_mean_ll_per_update": ll_last / N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
