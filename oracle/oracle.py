@@ -91,7 +91,7 @@ def mt_stream(seed, n):
 def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
         alpha, beta, learning_rate, learning_schedule, learning_exponent, max_samples, epochs,
         perms=None, rng_mode=RNG_MT19937, seed=REFERENCE_MT_SEED, epoch_begin=0, membership="linear",
-        has_uf=None, has_if=None, want_negatives=False, row_stripe=None, stripe_rows=0, pos_step=None, user_step=None, table_every=0, table_step=0.0,
+        has_uf=None, has_if=None, want_negatives=False, row_stripe=None, stripe_rows=0, pos_step=None, user_step=None, pos_step_bias=None, neg_step=None, table_every=0, table_step=0.0,
         table_head_every=0, table_head_rows=0):
     """Run the sequential restatement of `_fit` IN PLACE on the six weight arrays.
 
@@ -144,7 +144,13 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
         pos_step = np.ascontiguousarray(pos_step, dtype=np.float32)
         user_step = np.ascontiguousarray(user_step, dtype=np.float32)
         assert pos_step.shape == (I,) and user_step.shape == (U,)
-    rc = lib().rfm_oracle_fit_ex(*args, _p(pos_step, C.c_float), _p(user_step, C.c_float), _p(ll64, C.c_double))
+        if pos_step_bias is not None:       # (a scale of its own for the positive item's bias step)
+            pos_step_bias = np.ascontiguousarray(pos_step_bias, dtype=np.float32)
+            assert pos_step_bias.shape == (I,)
+        if neg_step is not None:            # (the scale of the NEGATIVE item's step)
+            neg_step = np.ascontiguousarray(neg_step, dtype=np.float32)
+            assert neg_step.shape == (I,)
+    rc = lib().rfm_oracle_fit_ex(*args, _p(pos_step, C.c_float), _p(user_step, C.c_float), _p(pos_step_bias, C.c_float), _p(neg_step, C.c_float), _p(ll64, C.c_double))
     if rc >= 100:
         raise AssertionError("[%s] are not finite" % _ARRAY_NAMES[rc - 100])
     if rc != 0:

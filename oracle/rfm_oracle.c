@@ -190,7 +190,7 @@ static int fit_impl(const rfm_oracle_params *p,
                     const float *x_uf, const float *x_if,
                     float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
                     const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe,
-                    const float *pos_step, const float *user_step, double *ll64_out) {
+                    const float *pos_step, const float *user_step, const float *pos_step_bias, const float *neg_step, double *ll64_out) {
     if (!p || p->N < 0 || p->I < 2 || p->F < 1 || p->max_samples < 1) return RFM_ORACLE_BAD_ARG;
     if (p->rng_mode == RFM_RNG_MT19937 && !perms && p->N > 0) return RFM_ORACLE_BAD_ARG;
     const int64_t N = p->N;
@@ -258,8 +258,10 @@ static int fit_impl(const rfm_oracle_params *p,
             /* (rfm_oracle_fit_ex: the engine's Hogwild step damping applied sequentially -- the positive item's step and
              *  the user's step are scaled, nothing else; both scales are 1 in rfm_oracle_fit) */
             const float eta_i = pos_step ? eta * pos_step[i] : eta, eta_u = user_step ? eta * user_step[u] : eta;
-            w_i[i] += eta_i * (sw * multiplier * (d_outer * 1.0f) - (d_reg_a * w_i[i]));  /* :279 */
-            w_i[j] += eta * (sw * multiplier * (d_outer * -1.0f) - (d_reg_a * w_i[j]));   /* :280 */
+            const float eta_iw = pos_step_bias ? eta * pos_step_bias[i] : eta_i;   /* (the bias of the positive item may be damped on its own) */
+            const float eta_j = neg_step ? eta * neg_step[j] : eta;                /* (the engine scales an item's step whichever side it is on) */
+            w_i[i] += eta_iw * (sw * multiplier * (d_outer * 1.0f) - (d_reg_a * w_i[i]));  /* :279 */
+            w_i[j] += eta_j * (sw * multiplier * (d_outer * -1.0f) - (d_reg_a * w_i[j]));   /* :280 */
 
             const float *xi = x_if + (size_t)i * Q, *xj = x_if + (size_t)j * Q, *xu = x_uf + (size_t)u * P;
             /* (analysis option; always 1 for the reference.  table_every < 0: the tables are frozen -- what the engine's row loop does
@@ -287,7 +289,7 @@ static int fit_impl(const rfm_oracle_params *p,
 
                 vu[f] += eta_u * (sw * multiplier * (d_outer * d_v_u) - (d_reg_a * vu[f])); /* :308 */
                 vi[f] += eta_i * (sw * multiplier * (d_outer * d_v_i) - (d_reg_a * vi[f])); /* :309 */
-                vj[f] += eta * (sw * multiplier * (d_outer * d_v_j) - (d_reg_a * vj[f]));   /* :310 */
+                vj[f] += eta_j * (sw * multiplier * (d_outer * d_v_j) - (d_reg_a * vj[f])); /* :310 */
 
                 if (p->has_uf && do_tab)                                           /* :313-318 (post-update v_i) */
                     for (int pp = 0; pp < P; ++pp) {
@@ -325,13 +327,15 @@ int rfm_oracle_fit(const rfm_oracle_params *p,
                    float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
                    const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe) {
     return fit_impl(p, interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
-                    perms, ll_out, neg_out, nsamp_out, row_stripe, NULL, NULL, NULL);
+                    perms, ll_out, neg_out, nsamp_out, row_stripe, NULL, NULL, NULL, NULL, NULL);
 }
 
 /* The extended entry point of the checker:
  *   pos_step, user_step (both or neither)  NOT the reference's algorithm any more: the same sequential loop with the engine's
  *              Hogwild step damping applied -- pos_step float [I] scales the POSITIVE item's step (bias and
- *              factor row; the engine's pos_scale), user_step float [U] the user's step (the engine's min(1, user_cap / degree)) --
+ *              factor row; the engine's pos_scale), user_step float [U] the user's step (the engine's min(1, user_cap / degree)),
+ *              pos_step_bias float [I] or NULL: a scale of its own for the positive item's BIAS step (NULL: pos_step's),
+ *              neg_step float [I] or NULL: the scale of the NEGATIVE item's step (bias and factor row; NULL: 1) --
  *              so that a test can separate what the damping changes (this against rfm_oracle_fit: a deliberate, documented change
  *              of the optimiser) from what asynchronous execution changes (the engine against this);
  *   ll64_out   double [epochs] or NULL: the epoch's log-likelihood summed in DOUBLE.  The reference accumulates it in a float
@@ -345,9 +349,9 @@ int rfm_oracle_fit_ex(const rfm_oracle_params *p,
                       const float *x_uf, const float *x_if,
                       float *w_i, float *w_if, float *v_u, float *v_i, float *v_uf, float *v_if,
                       const int32_t *perms, double *ll_out, int32_t *neg_out, int32_t *nsamp_out, const int32_t *row_stripe,
-                      const float *pos_step, const float *user_step, double *ll64_out) {
+                      const float *pos_step, const float *user_step, const float *pos_step_bias, const float *neg_step, double *ll64_out) {
     return fit_impl(p, interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
-                    perms, ll_out, neg_out, nsamp_out, row_stripe, pos_step, user_step, ll64_out);
+                    perms, ll_out, neg_out, nsamp_out, row_stripe, pos_step, user_step, pos_step_bias, neg_step, ll64_out);
 }
 
 /* _rankfm.pyx:106-116  (double accumulation like numpy's float64 `penalty`) */

@@ -193,6 +193,8 @@ struct Workspace {
     float *w_pad;                     // [n_items * kBiasStride] item biases, one 64-byte line each (SgdArgs::w_stride)
     float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: zero between launches
     unsigned int *feat_flags;     // [kFeatFlagWords] producer / trainer hand-shake of the features kernel (zero between launches)
+    unsigned int *tickets;        // [epochs, windows_per_epoch, kTicketWords] segment ticket heads, one set per launch
+    int64_t windows_per_epoch;
     size_t bytes;
 };
 
@@ -217,8 +219,14 @@ static size_t feat_ring_floats(const rfm_fit_config *c) {
     return 2 * (size_t)kFeatMaxProducers * gpb * (1 + 2 * (size_t)c->n_factors + (size_t)c->n_user_features + (size_t)c->n_item_features);
 }
 
+// launches an epoch can be cut into (rows_per_launch) + the opening launch of a fit with features: every launch has ticket heads of its own
+static int64_t ticket_windows(const rfm_fit_config *c) {
+    const int64_t w = c->rows_per_launch > 0 ? c->n_interactions / c->rows_per_launch + 3 : 2;
+    return w < 4096 ? w : 4096;        // (beyond that the launches fall back to the static segment stride)
+}
+
 static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_ring, int n_factors,
-                       int seg_rows_min) {
+                       int seg_rows_min, int64_t windows_per_epoch) {
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
@@ -241,6 +249,8 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.w_pad = (float *)(p + o);                  o += align_up(sizeof(float) * (size_t)kBiasStride * (size_t)n_items);
     w.hot_bins_v = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot * (size_t)n_factors);
     w.hot_bins_w = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot);
+    w.windows_per_epoch = windows_per_epoch;
+    w.tickets = (unsigned int *)(p + o);         o += align_up(sizeof(unsigned int) * kTicketWords * (size_t)windows_per_epoch * (size_t)epochs);
     w.bytes = o;
     return w;
 }
@@ -260,8 +270,10 @@ static int validate(const rfm_fit_config *c) {
     if (c->learning_schedule != RFM_SCHEDULE_CONSTANT && c->learning_schedule != RFM_SCHEDULE_INVSCALING)
         return RFM_ERR_UNKNOWN_SCHEDULE;
     if (c->mode != RFM_MODE_HOGWILD && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;
-    if (c->tune_segment_rows < 0 || c->tune_segment_rows > kSegmentRows || c->tune_stripe_window < 0 || c->tune_stripe_rows < -1 ||
-        c->tune_hot_publications < 0 || c->tune_feature_waves < 0 || c->tune_table_producers < 0 || c->tune_reserved[0] ||
+    if (c->tune_segment_rows < 0 || c->tune_segment_rows > kSegmentRows || c->tune_stripe_window < 0 || c->tune_stripe_window > 4096 ||
+        c->tune_stripe_rows < -1 || c->tune_stripe_rows > 4096 || c->tune_hot_publications < 0 || c->tune_hot_publications > 65536 ||
+        c->tune_feature_waves < 0 || c->tune_feature_waves > 16 || c->tune_table_producers < 0 || c->tune_table_producers > kFeatMaxProducers ||
+        c->tune_reserved[0] ||
         (c->sampler != RFM_SAMPLER_UNIFORM && c->sampler != RFM_SAMPLER_STRIPES))
         return RFM_ERR_BAD_ARG;
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
@@ -438,7 +450,7 @@ int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps)
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
-    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg)).bytes;
+    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg), ticket_windows(cfg)).bytes;
 }
 
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
@@ -451,7 +463,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     if ((rc = device_ok()) != RFM_OK) return rc;
     const int E = cfg->epochs;
     const int64_t N = cfg->n_interactions;
-    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg));
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg), ticket_windows(cfg));
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
@@ -549,12 +561,25 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     // A saturated user (every item in the list) would make the rejection sampler of EVERY one of its rows run to its attempt limit
     // before the error comes back -- minutes on a 70-row user -- so the verdict of the degree check is read before anything is
     // launched (one 4-byte read-back per call that checked; the reference spins forever at rankfm/_rankfm.pyx:250-253).
-    if (cfg->plan_token <= 0) {
+    // (only when a list CAN hold every item: some degree >= I -- known exactly when the offsets are on the host for the plan, else
+    // bounded by N >= I; every other call skips the synchronisation)
+    bool may_saturate = N >= (int64_t)cfg->n_items;
+    if (may_saturate && !off.empty()) {
+        may_saturate = false;
+        for (int u = 0; u < cfg->n_users && !may_saturate; ++u) may_saturate = off[(size_t)u + 1] - off[u] >= (int64_t)cfg->n_items;
+    }
+    if (cfg->plan_token <= 0 && may_saturate) {
         unsigned int flags = 0;
         RFM_HIP(hipMemcpyAsync(&flags, ws.error_flags, sizeof flags, hipMemcpyDeviceToHost, stream));
         RFM_HIP(hipStreamSynchronize(stream));
         if (flags & 2u) {
-            if (rep) { rep->epochs_done = 0; rep->nonfinite_array = -1; rep->plan_token = 0; }
+            if (rep) {            // (nothing ran: every scalar field of the report says so, the caller's arrays stay untouched)
+                rfm_fit_report z;
+                memset(&z, 0, sizeof z);
+                z.log_likelihood = rep->log_likelihood; z.reg_penalty = rep->reg_penalty; z.sgd_kernel_ms = rep->sgd_kernel_ms; z.n_draws = rep->n_draws;
+                z.nonfinite_array = -1;
+                *rep = z;
+            }
             return RFM_ERR_USER_SATURATED;
         }
     }
@@ -674,6 +699,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             const int64_t room = std::max<int64_t>(cap, 3);
             n_producers = grid >= 64 ? 3 : (grid >= 4 ? 2 : 1);
             if (cfg->tune_table_producers > 0) n_producers = std::min(kFeatMaxProducers, cfg->tune_table_producers);
+            // the trainer, its producers and at least one row loop must all be RESIDENT (they hand-shake by spinning): never more
+            // producers than the launch's room leaves beside one trainer and one row-loop workgroup
+            n_producers = (int)std::max<int64_t>(1, std::min<int64_t>(n_producers, room - 2));
             if (grid + 1 + n_producers > room) grid = (int)std::max<int64_t>(1, room - 1 - n_producers);
             grid += 1 + n_producers;
         }
@@ -813,6 +841,13 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.stripe_cover = stripe_rows > 0 ? std::min(1.0f, (float)grid * (float)stripe_rows / (float)cfg->n_items) : 0.0f;
         a.block_threads = waves_per_block * 64;
         a.feat_ring = ws.feat_ring; a.feat_flags = ws.feat_flags; a.n_producers = n_producers; a.feat_frozen = feat_frozen ? 1 : 0;
+        a.tickets = nullptr;
+        a.damp_positive_only = (cfg->debug_flags & 256) ? 1 : 0;
+        // ticket heads of launch `w` of this epoch (dynamic segment order; debug_flags bit 7 keeps the static stride)
+        const bool use_tickets = use_segments && !use_stripes && !single_group && !(cfg->debug_flags & 128);
+        auto tickets_of = [&](int w) -> unsigned int * {
+            return use_tickets && w < ws.windows_per_epoch ? ws.tickets + ((size_t)e * ws.windows_per_epoch + w) * kTicketWords : nullptr;
+        };
         // rankfm/_rankfm.pyx:220-223: pow() in double, narrowed to the float `eta`
         a.eta = cfg->learning_schedule == RFM_SCHEDULE_CONSTANT
                     ? cfg->learning_rate
@@ -861,6 +896,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             a.pos_begin = u_begin;
             a.pos_end = u_begin + head_units;
             a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * head_rowloops ? 1 : 0;
+            a.tickets = tickets_of((int)a.launch_index);
             launch(a, 1 + n_producers + head_rowloops, stream);
             a.hot_direct = saved_direct;
         }
@@ -868,6 +904,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             a.launch_index = (uint32_t)window;
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
+            a.tickets = tickets_of(window);
             launch(a, grid, stream);
         }
         if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);
@@ -915,6 +952,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     int epochs_done = E, bad_array = -1;
     if (h_err[0] & 3u) status = RFM_ERR_USER_SATURATED;
     if (h_err[0] & 8u) { g_last_error = "features kernel: a workgroup gave up waiting for the table trainer / a step producer"; status = RFM_ERR_HIP; }
+    if (h_err[0] & 16u) { g_last_error = "segment tickets: a row group gave up waiting for its workgroup's next chunk of the epoch's order"; status = RFM_ERR_HIP; }
     for (int e = 0; e < epochs_launched && status == RFM_OK; ++e) {
         if (cfg->check_finite && h_nonfinite[e]) {
             for (int k = 0; k < 6; ++k)

@@ -102,7 +102,12 @@ struct SgdArgs {
     unsigned int *feat_flags;
     int32_t n_producers;
     int32_t feat_frozen;                        // debug: the feature tables are not trained (no trainer, no producers)
+    // dynamic segment order (segments kernel without stripes, pipelined feature row loop): a row group takes its next segment from
+    // a ticket counter instead of striding the order with the number of groups (SegmentTickets below); nullptr = static stride
+    unsigned int *tickets;                      // the launch's counter of order positions handed out, zero at launch
+    int32_t damp_positive_only;                 // experiments: the round-3 rule (an item's scale applies to its step as the POSITIVE item only)
 };
+constexpr int kTicketWords = 16;                // one counter per launch, on a 64-byte line of its own
 constexpr int kHotBins = 16;
 
 constexpr size_t kLdsBytes = 160 * 1024;        // per workgroup on gfx950
@@ -597,11 +602,13 @@ struct RowStep {
             if (STRIPE || a.pos_scale) {
                 // (stripe launches always carry bias and step scale in the item's padded line: scale 1 when nothing is damped)
                 pos_scale_i = (STRIPE || pre) ? pre->scale : a.pos_scale[i];
-                if constexpr (HOT) {
-                    if (pos_scale_i >= 2.0f) {
-                        slot = (int)(pos_scale_i * 0.5f) - 1;
-                        pos_scale_i -= 2.0f * (float)(slot + 1);
-                    }
+                // a hot item's entry carries its accumulator slot above the scale (SgdArgs::hot_item).  EVERY instantiation decodes
+                // it: the plan of a launch is shared by kernels with and without accumulators (the step producers of the features
+                // kernel score hot items through this generic step -- undecoded, their staged steps were up to ~130 x too long)
+                if (pos_scale_i >= 2.0f) {
+                    const int sl = (int)(pos_scale_i * 0.5f) - 1;
+                    pos_scale_i -= 2.0f * (float)(sl + 1);
+                    if constexpr (HOT) slot = sl;
                 }
             }
         }
@@ -767,6 +774,19 @@ struct RowStep {
             }
         }
         const float pu = min_pu;                                          // :267-268
+        // Hogwild step damping is a property of the ITEM, whichever side of the pair it is on: the chosen negative's step takes its
+        // item's scale too.  (Rounds 1-3 scaled the positive's step only: that moves the fixed point of a hot item's bias -- its upward
+        // pushes weigh less than its downward ones -- and alone accounted for the whole +1.9 % log-likelihood / +2.7 % |w_i| deviation
+        // of config 3 from the reference algorithm; with both sides scaled the sequential stand-in sits within 0.01 % / 0.1 %,
+        // profiles/r04_notes.md.)  Same line as the bias just read (padded table) or the plan's scale array.
+        float neg_scale_j = 1.0f;
+        if constexpr (!SERIAL) {
+            if (STRIPE || a.pos_scale) {
+                float sc = (STRIPE || a.scale_in_pad) ? a.w_i[(size_t)j * a.w_stride + 1] : a.pos_scale[j];
+                if (sc >= 2.0f) sc -= 2.0f * floorf(sc * 0.5f);           // (a hot item's entry carries its slot above the scale)
+                neg_scale_j = sc;
+            }
+        }
         const float multiplier = a.multiplier[sampled];                   // :269 (integer division inside the log)
         float log_sig, d_outer;
         sigmoid_terms(pu, log_sig, d_outer);                              // :270, :276
@@ -774,6 +794,7 @@ struct RowStep {
         const float g = sw * multiplier;
         const float eta = a.eta, reg_a = a.reg_a, reg_b = a.reg_b;
         float eta_u = eta, eta_i = eta, eta_f = eta;
+        const float eta_j = a.damp_positive_only ? eta : eta * neg_scale_j;
         if constexpr (!SERIAL) {
             if constexpr (STRIPE) eta_u = eta * user_scale;          // (per segment: load_ulist)
             else eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
@@ -792,11 +813,11 @@ struct RowStep {
                 const float g_i = vu[k];                                             // :293-294 (d_v_j = -d_v_i)
                 const float d_u = eta_u * (g * (d_outer * g_u) - reg_a * vu[k]);     // :308
                 d_i[k] = eta_i * (g * (d_outer * g_i) - reg_a * vi[k]);              // :309
-                d_j[k] = eta * (g * (d_outer * -g_i) - reg_a * vj[k]);               // :310
+                d_j[k] = eta_j * (g * (d_outer * -g_i) - reg_a * vj[k]);             // :310
                 vu[k] += d_u;
             }
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);           // :279
-            const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);            // :280
+            const float dwj = eta_j * (g * (d_outer * -1.0f) - reg_a * wj);         // :280
             if (HOT && slot >= 0) {
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) hot_add(hot_acc + slot * F + dword_f(k), d_i[k]);
@@ -831,7 +852,7 @@ struct RowStep {
         // item biases (:279-280) -- one lane per group
         if (UPD_ROWS && sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
-            const float dwj = eta * (g * (d_outer * -1.0f) - reg_a * wj);
+            const float dwj = eta_j * (g * (d_outer * -1.0f) - reg_a * wj);
             if (HOT && slot >= 0) hot_add(hot_accw + slot, dwi);
             else apply_f32<SERIAL>(a.w_i + (size_t)i * a.w_stride, wi, dwi);
             if (STRIPE && jrow >= 0) {
@@ -848,7 +869,7 @@ struct RowStep {
             if constexpr (FEAT) { g_i += A[k]; g_u += Bi[k] - Bj[k]; }   // :297-305
             const float d_u = eta_u * (g * (d_outer * g_u) - reg_a * vu[k]);   // :308
             const float d_i = eta_i * (g * (d_outer * g_i) - reg_a * vi[k]);   // :309
-            const float d_j = eta * (g * (d_outer * -g_i) - reg_a * vj[k]);    // :310
+            const float d_j = eta_j * (g * (d_outer * -g_i) - reg_a * vj[k]);  // :310
             nvu[k] = vu[k] + d_u;
             dij[k] = (vi[k] + d_i) - (vj[k] + d_j);
             if (UPD_ROWS && dword_ok(k)) {
@@ -969,6 +990,56 @@ __device__ __forceinline__ void flush_counters(const SgdArgs &a, double ll_acc, 
         if (draw_acc) atomicAdd(a.draws, (unsigned long long)draw_acc);
     }
 }
+
+// Dynamic segment order.  With a static stride (group g walks order positions g, g + n_groups, ...) a group's share of an epoch is
+// ~12 segments of 8 ... 32 rows: on config 2 the busiest group has 1.20 x the mean rows and the launch waits for it (utilisation
+// 0.84 if every row cost the same; a greedy hand-out reaches 0.94).  So a group that finishes a segment takes the NEXT position of
+// the epoch's keyed order from a counter.  The hand-out has two levels: a WORKGROUP draws chunks of kTicketChunk consecutive order
+// positions from the launch's counter in memory (one returning atomic per chunk), its row groups take single positions out of the
+// chunk through a counter in LDS.  (A returning memory-side atomic per SEGMENT was measured first and made config 2 7 % SLOWER:
+// loads and returning atomics come back in order, so every vector load the wavefront issues behind the ticket request -- the rows of
+// all four of its groups -- waits out the atomic's fabric round trip.  LDS atomics are counted separately and hold nothing up.)
+// The chunk AFTER the current one is requested by whoever draws the first ticket of a chunk, so nobody waits for a chunk in the
+// steady state.  The draws are keyed by CSR position and the segment order by position in the epoch's order, so which group works
+// on a segment changes neither; the realised interleaving is closer to the order's own sequence than the static stride's.
+constexpr int kTicketChunk = 16;
+// chunks whose {base, number} a workgroup keeps in LDS at a time.  A row group holds at most one ticket it has not finished looking
+// up, so the tickets "in the air" of a workgroup span at most (row groups per workgroup) + kTicketChunk positions -- 272 with 4-lane
+// row groups -- and a ring of 32 chunks (512 tickets) can never be lapped.  (A ring of 4 was: when all 64 groups of a workgroup draw
+// at once -- the launch's first tickets -- the opener of chunk 3 published chunk 4 over chunk 0's slot while the opener of chunk 0
+// was still away fetching chunk 1, and that lane then waited for a chunk number that was gone: a hang, one run in three.)
+constexpr int kTicketRing = 32;
+constexpr int kTicketLdsWords = 1 + 2 * kTicketRing;
+struct SegmentTickets {
+    lds_int *q;               // LDS: [0] tickets handed out by this workgroup | [1, 1 + ring) chunk bases | [1 + ring, 1 + 2 ring) chunk numbers + 1
+    // (thread 0, before the workgroup's first barrier)
+    __device__ __forceinline__ void init_block(const SgdArgs &a) {
+        q[0] = 0;
+        for (int k = 0; k < kTicketRing; ++k) q[1 + kTicketRing + k] = 0;
+        q[1] = (int)__hip_atomic_fetch_add(a.tickets, (unsigned)kTicketChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q[1 + kTicketRing] = 1;
+    }
+    // the next order position of the launch for this group, or -1 when none is left (lane 0 of the group only; the caller broadcasts)
+    __device__ __forceinline__ int64_t take(const SgdArgs &a) {
+        const unsigned t = (unsigned)__hip_atomic_fetch_add(q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned c = t / kTicketChunk, o = t % kTicketChunk;
+        // this ticket's own chunk FIRST (it was requested when chunk c - 1 was opened, tens of microseconds ago in the steady state) ...
+        lds_int *tag = q + 1 + kTicketRing + (c % kTicketRing);
+        unsigned spin = 0;
+        while ((unsigned)__hip_atomic_load(tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != c + 1u) {
+            if (++spin > (1u << 22)) { atomicOr(a.error_flags, 16u); return -1; }      // (a hang guard, never observed)
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const int64_t p = a.pos_begin + (int64_t)(unsigned)__hip_atomic_load(q + 1 + (c % kTicketRing), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + (int64_t)o;
+        // ... then the duty of a chunk's first ticket: request chunk c + 1 for those who come next
+        if (o == 0) {
+            const unsigned b = __hip_atomic_fetch_add(a.tickets, (unsigned)kTicketChunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 1 + ((c + 1) % kTicketRing), (int)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(q + 1 + kTicketRing + ((c + 1) % kTicketRing), (int)(c + 2), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return p < a.pos_end ? p : -1;
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // rows kernel: every wavefront walks the epoch's positions with a grid stride of (waves * rows-per-wave)
@@ -1157,9 +1228,26 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
 
     double ll_acc = 0.0;
     unsigned draw_acc = 0;
+    const int lane_base = lane - sub;
     int64_t sp = a.pos_begin + (a.single_group ? 0 : group);      // position in the epoch's segment order
     const int64_t stride = a.single_group ? 1 : n_groups;
     bool active = sp < a.pos_end && (a.single_group ? group == 0 : group < n_groups);
+    // dynamic segment order (SegmentTickets): stripe launches keep the static stride, their window schedule is a function of it
+    const bool dynamic = !STRIPE && a.tickets != nullptr && !a.single_group;
+    SegmentTickets tickets;
+    __shared__ int s_ticket_q[kTicketLdsWords];
+    tickets.q = (lds_int *)s_ticket_q;
+    if constexpr (!STRIPE) {
+        if (dynamic) {
+            if (threadIdx.x == 0) tickets.init_block(a);
+            __syncthreads();
+            active = group < n_groups && a.pos_begin < a.pos_end;
+            int64_t first = -1;
+            if (active && sub == 0) first = tickets.take(a);
+            sp = __shfl(first, lane_base);
+            active = active && sp >= 0;
+        }
+    }
     bool have = false;
     int32_t u = 0, begin = 0, len = 0, t = 0, len_bits = 0;
     uint32_t seg_key = 0;
@@ -1171,7 +1259,6 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
     int32_t seg_item[SEGR], seg_pos[SEGR];
     float seg_sw[SEGR];
     typename Step::PosRow cur_pos, next_pos;
-    const int lane_base = lane - sub;
     // row t of the segment: register t / G of lane t % G (the register index is selected, not indexed: registers stay registers).
     // 16-lane groups are DPP rows: the registers are ROTATED one lane per processed row (seg_rotate), so the current row is
     // always in lane 0 and the next one in lane 1 of the selected register -- a row_share move, no LDS shuffle and no index math.
@@ -1224,7 +1311,14 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
         }
         if constexpr (HOT) {
             // bin sweeping duty (see SgdArgs::hot_bins_v): the wavefronts of a workgroup take turns, one turn per row; a turn
-            // sweeps the workgroup's lines (at most four, else the host chose hot_direct)
+            // sweeps the workgroup's lines (at most four, else the host chose hot_direct).
+            // (Round 4 tried the sweep in two halves -- the exchanges issued at the top of the row, their sum added at its bottom, one
+            // line per turn -- to take the fabric round trip out of the sweeping wavefront's path: no faster once the segments are
+            // handed out dynamically (2.89 against 2.79 ms on config 2), and the first epoch's log-likelihood moved from +0.6 % to
+            // +3.3 % against the oracle, the hottest biases' bins being swept half as often; and a sweep WITHOUT returning atomics --
+            // system-scope loads, then subtracting what was read -- diverged: a bin that reads as zero is not written by its sweeper,
+            // its line stays in the sweeper's L2, and the memory-side atomics of the publishers in the other XCDs never invalidate
+            // it.  profiles/r04_notes.md.)
             const int n_waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
             if (!a.hot_direct && iter % n_waves == wave)
                 for (int line = blockIdx.x; line < hot_lines(a); line += gridDim.x) hot_sweep_line(a, line);
@@ -1281,8 +1375,20 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
                 for (int k = 0; k < KPL; ++k)
                     if (STRIPE || sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
                 have = false;
-                sp += stride;
-                active = sp < a.pos_end;
+                bool stepped = false;
+                if constexpr (!STRIPE) {
+                    if (dynamic) {
+                        int64_t nxt = -1;
+                        if (sub == 0) nxt = tickets.take(a);
+                        sp = __shfl(nxt, lane_base);
+                        active = sp >= 0;
+                        stepped = true;
+                    }
+                }
+                if (!stepped) {
+                    sp += stride;
+                    active = sp < a.pos_end;
+                }
             }
         }
     }
@@ -1879,6 +1985,20 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
             for (int k = 1; k < SEGR; ++k) x = ((unsigned)tt / G == (unsigned)k) ? r[k] : x;
             return x;
         };
+        // dynamic segment order (SegmentTickets)
+        const bool dynamic = a.tickets != nullptr && !a.single_group;
+        SegmentTickets tickets;
+        __shared__ int s_ticket_q[kTicketLdsWords];
+        tickets.q = (lds_int *)s_ticket_q;
+        if (dynamic) {
+            if (threadIdx.x == 0) tickets.init_block(a);
+            __syncthreads();
+            active = group < n_groups && a.pos_begin < a.pos_end;
+            int64_t first = -1;
+            if (active && sub == 0) first = tickets.take(a);
+            sp = __shfl(first, lane_base);
+            active = active && sp >= 0;
+        }
         for (int iter = 0; __any(active); ++iter) {
             // Every wavefront keeps a slice of the workgroup's copy fresh, a part of it per row: the loads are issued here and land in
             // LDS at the END of the row, so that their latency (system-scope loads go to memory) is the row's, not an extra round
@@ -1957,7 +2077,17 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                 float vj[KPL], wj, xj0 = 0.0f, xj1 = 0.0f;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) vj[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_i + (size_t)j * F + sub + G * k) : 0.0f;
-                wj = load_f32<FRESH>(a.w_i + (size_t)j * a.w_stride);
+                // (bias and the item's step scale -- the damping scales an item's step on either side of the pair, RowStep -- in one request)
+                float neg_scale_j = 1.0f;
+                if (a.scale_in_pad) {
+                    const float x = load_f32<FRESH>(a.w_i + (size_t)j * a.w_stride + (sub & 1));
+                    wj = __shfl(x, lane_base);
+                    neg_scale_j = __shfl(x, lane_base + 1);
+                } else {
+                    wj = load_f32<FRESH>(a.w_i + (size_t)j * a.w_stride);
+                    if (a.pos_scale) neg_scale_j = a.pos_scale[j];
+                }
+                if (neg_scale_j >= 2.0f) neg_scale_j -= 2.0f * floorf(neg_scale_j * 0.5f);
                 if (a.has_if) {
                     const float *x = a.x_if + (size_t)j * a.n_if;
                     if (sub < a.n_if) xj0 = x[sub];
@@ -1984,7 +2114,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                 sigmoid_terms(pu, log_sig, d_outer);                              // :270, :276
                 if (sub == 0) { ll_acc += (double)log_sig; draw_acc += 1u; }
                 const float g = sw * multiplier;
-                const float eta_u = eta * step.user_scale, eta_i = eta * cur.scale;
+                const float eta_u = eta * step.user_scale, eta_i = eta * cur.scale, eta_j = a.damp_positive_only ? eta : eta * neg_scale_j;
                 float *pi = a.v_i + (size_t)i * F + sub, *pj = a.v_i + (size_t)j * F + sub;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) {
@@ -1992,7 +2122,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                     const float g_i = vu[k] + A[k];                                                   // :293-294, :297-300
                     const float d_u = eta_u * (g * (d_outer * g_u) - reg_a * vu[k]);                  // :308
                     const float d_i = eta_i * (g * (d_outer * g_i) - reg_a * cur.v[k]);               // :309
-                    const float d_j = eta * (g * (d_outer * -g_i) - reg_a * vj[k]);                   // :310
+                    const float d_j = eta_j * (g * (d_outer * -g_i) - reg_a * vj[k]);                 // :310
                     vu[k] += d_u;
                     if (sub + G * k < F) {
                         if (slot >= 0) __hip_atomic_fetch_add(hot_acc + slot * F + sub + G * k, __float2int_rn(d_i * hot_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2004,7 +2134,7 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                     const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * cur.w);                                  // :279
                     if (slot >= 0) __hip_atomic_fetch_add(hot_accw + slot, __float2int_rn(dwi * hot_scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else atomic_add_f32(a.w_i + (size_t)i * a.w_stride, dwi);
-                    atomic_add_f32(a.w_i + (size_t)j * a.w_stride, eta * (g * (d_outer * -1.0f) - reg_a * wj));        // :280
+                    atomic_add_f32(a.w_i + (size_t)j * a.w_stride, eta_j * (g * (d_outer * -1.0f) - reg_a * wj));      // :280
                 }
                 // every hot_period-th toucher of a slot publishes what the workgroup has accumulated for it (a keyed coin, RowStep)
                 if (slot >= 0 && __umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)a.hot_period[slot]) == 0u) {
@@ -2028,8 +2158,15 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                         if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
                     if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                     have = false;
-                    sp += stride;
-                    active = sp < a.pos_end;
+                    if (dynamic) {
+                        int64_t nx = -1;
+                        if (sub == 0) nx = tickets.take(a);
+                        sp = __shfl(nx, lane_base);
+                        active = sp >= 0;
+                    } else {
+                        sp += stride;
+                        active = sp < a.pos_end;
+                    }
                 }
             }
             if (trains) {

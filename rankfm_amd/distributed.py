@@ -367,6 +367,14 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     # full on every rank (numpy's stream must advance identically).
     assert isinstance(interactions, (np.ndarray, pd.DataFrame)), "[interactions] must be np.ndarray or pd.dataframe"
     assert interactions.shape[1] == 2, "[interactions] should be: [user_id, item_id]"
+    # the device is resolved BEFORE the first collective: under RCCL every rank must communicate on ITS GPU, also for a caller who
+    # passes device=cuda:local_rank without having called torch.cuda.set_device (all ranks on cuda:0 = duplicate-GPU error or a hang)
+    if make_trainer is None:
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        device = torch.device(device)
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
     if world > 1:
         from .utils import get_data
         data = get_data(interactions)
@@ -376,7 +384,8 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
         dist.all_gather_object(uniq, (pd.unique(data[r_lo:r_hi, 0]), pd.unique(data[r_lo:r_hi, 1])), group=group)
         model._set_ids(np.sort(pd.unique(np.concatenate([u for u, _ in uniq]))), np.sort(pd.unique(np.concatenate([i for _, i in uniq]))))
         mine = model._index_pairs(data[r_lo:r_hi], None)
-        comm_dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        comm_dev = (device if isinstance(device, torch.device) and device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())) \
+            if dist.get_backend(group) == "nccl" else torch.device("cpu")
         longest = max(n_rows * (r + 1) // world - n_rows * r // world for r in range(world))
         buf = torch.zeros((max(longest, 1), 2), dtype=torch.int32, device=comm_dev)
         buf[:len(mine)] = torch.as_tensor(mine).to(comm_dev)
@@ -384,8 +393,10 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
         dist.all_gather(parts, buf, group=group)
         pairs = np.concatenate([parts[r][:n_rows * (r + 1) // world - n_rows * r // world].cpu().numpy() for r in range(world)])
         if sample_weight is not None:
-            assert isinstance(sample_weight, (np.ndarray, pd.Series)) and sample_weight.ndim == 1 and len(sample_weight) == n_rows, \
-                "[sample_weight] must be a vector as long as [interactions]"
+            # (the same three checks, with the same messages, as RankFM._index_pairs makes on the single-process path)
+            assert isinstance(sample_weight, (np.ndarray, pd.Series)), "[sample_weight] must be np.ndarray or pd.series"
+            assert sample_weight.ndim == 1, "[sample_weight] must a vector (ndim=1)"
+            assert len(sample_weight) == n_rows, "[sample_weight] must have the same length as [interactions]"
             model.sample_weight = np.ascontiguousarray(get_data(sample_weight), dtype=np.float32)
         else:
             model.sample_weight = np.ones(n_rows, dtype=np.float32)
@@ -412,8 +423,6 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
                  learning_exponent=model.learning_exponent, max_samples=max_samples)
     tables = {k: getattr(model, k) for k in SHARED_NAMES}
     if make_trainer is None:
-        if device is None:
-            device = torch.device("cuda", torch.cuda.current_device())
         seed = int(np.random.randint(0, 2**31 - 1)) + rank if model.engine.seed is None else int(model.engine.seed) + rank
         trainer, sess = make_device_trainer(shard, tables, model.x_if, hyper, device, group=group, merge_damping=merge_damping,
                                             syncs_per_epoch=syncs_per_epoch, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),

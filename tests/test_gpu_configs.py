@@ -50,7 +50,7 @@ def _trained_then_one_epoch(oracle, sh, max_samples, warm_epochs, seed, lr=0.1, 
     if damped:
         pos_step, user_step = sess.step_scales()
         od = {k: v.copy() for k, v in w0.items()}
-        outd = _oracle_epoch(oracle, sh, od, max_samples, warm_epochs, seed, lr, sess.geometry(), pos_step=pos_step, user_step=user_step)
+        outd = _oracle_epoch(oracle, sh, od, max_samples, warm_epochs, seed, lr, sess.geometry(), pos_step=pos_step, user_step=user_step, neg_step=pos_step)
         return w0, g, rep, o, out, warm, (od, outd)
     return w0, g, rep, o, out, warm
 

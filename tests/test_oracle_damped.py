@@ -68,6 +68,36 @@ def test_one_damped_step_by_hand(oracle):
     np.testing.assert_allclose(g["w_i"][j], w["w_i"][j] + eta * (-mult * d - reg * w["w_i"][j]), rtol=2e-6, atol=1e-9)
 
 
+def test_negative_side_scale_by_hand(oracle):
+    """`neg_step` (the engine scales an item's step whichever side of the pair it is on): the same single interaction with the drawn
+    negative's step scaled -- bias and factor row -- and nothing else changed"""
+    pairs1 = np.array([[0, 0]], np.int32)
+    from rankfm_amd._rankfm import UserItemsCSR
+    csr1 = UserItemsCSR.from_pairs(pairs1[:, 0], pairs1[:, 1], 1)
+    w = synthetic.init_weights(1, 3, 4, seed=6)
+    for k in ("v_u", "v_i"):
+        w[k] = (w[k] * 30).astype(np.float32)
+    s_j, eta, alpha = 0.125, 0.1, 0.01
+    one_i, one_u = np.ones(3, np.float32), np.ones(1, np.float32)
+    plain, out = _fit(oracle, w, pairs1, csr1, epochs=1, pos_step=one_i, user_step=one_u, want_negatives=True)
+    g, out2 = _fit(oracle, w, pairs1, csr1, epochs=1, pos_step=one_i, user_step=one_u, neg_step=np.full(3, s_j, np.float32), want_negatives=True)
+    j = int(out["neg"][0, 0])
+    assert int(out2["neg"][0, 0]) == j
+    vu, vi, vj = (w["v_u"][0].astype(np.float64), w["v_i"][0].astype(np.float64), w["v_i"][j].astype(np.float64))
+    pu = (w["w_i"][0] + vu @ vi) - (w["w_i"][j] + vu @ vj)
+    d = 1.0 / (np.exp(pu) + 1.0)
+    mult = np.log((3 - 1) // 1) / np.log(3)
+    reg = 2 * alpha
+    np.testing.assert_allclose(g["v_i"][j], vj + s_j * eta * (mult * d * -vu - reg * vj), rtol=2e-6)
+    np.testing.assert_allclose(g["w_i"][j], w["w_i"][j] + s_j * eta * (-mult * d - reg * w["w_i"][j]), rtol=2e-6, atol=1e-9)
+    for k in ("v_u",):
+        assert np.array_equal(g[k], plain[k])                       # the user's and the positive's steps are untouched
+    assert np.array_equal(g["v_i"][0], plain["v_i"][0]) and g["w_i"][0] == plain["w_i"][0]
+    # unit negative scales are the plain damped loop bit for bit
+    h, _ = _fit(oracle, w, pairs1, csr1, epochs=1, pos_step=one_i, user_step=one_u, neg_step=one_i)
+    assert all(np.array_equal(h[k], plain[k]) for k in plain)
+
+
 def test_ll64_is_the_float_accumulators_sum_without_its_rounding(oracle):
     """`ll` restates the reference's float accumulator (rankfm/_rankfm.pyx:228, :270); `ll64` sums the same terms in double.  On a
     small problem they agree to float precision; the divergence at millions of rows (the accumulator's spacing passes the size of

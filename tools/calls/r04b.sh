@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 4, GPU call B: parity of chunked tickets / pipelined exchange sweeps / symmetric damping, A/B timings, LL from the initial weights
+cd ${GRAFT_REPO_ROOT:-.}
+O=gpurun_out/r04b; mkdir -p $O
+( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge.py -x -q -m gpu ) > $O/parity.log 2>&1; tail -3 $O/parity.log
+( timeout 300 python tools/ab_kernel.py --config C2 --variants "base;flags=128;flags=256;flags=384" --epochs 6 --rounds 3 ) > $O/ab_c2.log 2>&1; tail -4 $O/ab_c2.log
+( timeout 300 python tools/ab_kernel.py --config C4 --variants "base;flags=128;flags=256;flags=384" --epochs 4 --rounds 2 ) > $O/ab_c4.log 2>&1; tail -4 $O/ab_c4.log
+( timeout 300 python tools/ab_kernel.py --config C3 --variants "base;flags=128;damping=64;damping=256" --warmup 0 --epochs 4 --rounds 1 --print-ll ) > $O/ab_c3.log 2>&1; tail -8 $O/ab_c3.log
+( timeout 300 python tools/ab_kernel.py --config C2 --variants "base;damping=64;damping=256;damping=512" --warmup 0 --epochs 4 --rounds 1 --print-ll ) > $O/ab_c2_damp.log 2>&1; tail -8 $O/ab_c2_damp.log

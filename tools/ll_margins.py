@@ -50,7 +50,7 @@ def oracle_task(spec):
         extra.update(order.oracle_stripes(d["csr_offsets"], spec["seed"], epochs, geo, len(w["w_i"])))
     if spec.get("steps"):
         s = np.load(spec["steps"])
-        extra.update(pos_step=s["pos"], user_step=s["user"])
+        extra.update(pos_step=s["pos"], user_step=s["user"], neg_step=s["pos"])      # (an item's scale applies on either side of the pair)
     t0 = time.time()
     out = orc.fit(d["pairs_csr"], d["sw_csr"], d["csr_offsets"], d["csr_items"], d["x_uf"], d["x_if"], w["w_i"], w["w_if"], w["v_u"], w["v_i"],
                   w["v_uf"], w["v_if"], 0.01, 0.1, spec["lr"], "constant", 0.25, spec["max_samples"], len(epochs), perms=perms,
