@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RFM_ABI_VERSION 3
+#define RFM_ABI_VERSION 4
 
 typedef enum rfm_status {
     RFM_OK = 0,
@@ -135,7 +135,8 @@ typedef struct rfm_fit_config {
     int32_t tune_table_producers;      /* features kernel: step-producer workgroups feeding the table trainer, 1..16 (auto: 3 on a
                                       full chip, 2 / 1 on small launches) */
     int32_t sampler;               /* RFM_SAMPLER_* (0 = the reference's uniform sampler) */
-    int32_t tune_reserved[1];      /* must be 0 */
+    int32_t tune_table_every;      /* features kernel: the table trainer applies rows-of-the-launch / this many staged steps per launch
+                                      (auto: 1.25 x the launch's row-loop workgroups, the pace a trainer keeps beside them; 20 in the opening launch) */
 } rfm_fit_config;
 
 /* All pointers of one struct live in the same memory space: device memory for the *_device entry
@@ -184,6 +185,10 @@ typedef struct rfm_fit_report {
     int64_t feat_diag[8];          /* features kernel, microseconds over the call: the trainer waited for a batch | ran in all |
                                       the producers waited for a free slot (summed) | ran in all (summed) | the trainer's apply |
                                       publication | batch into LDS | slot release */
+    int64_t table_overlap_us;      /* features kernel, last launch of the call: microseconds during which the table trainer's kernel and the
+                                      row-loop kernel (two streams) were BOTH running; -1 = no trainer.  Near 0 = the two did not overlap
+                                      (a profiler that serialises kernels, a device without room): the tables then were trained before the rows */
+    int64_t table_span_us[2];      /* ... and how long each ran: tables kernel | row-loop kernel */
 } rfm_fit_report;
 
 int rfm_abi_version(void);

@@ -22,3 +22,21 @@ def fit_planted(args):
             m.v_if, m.alpha, m.beta, m.learning_rate, m.learning_schedule, m.learning_exponent, 1, epochs, perms=None,
             rng_mode=orc.RNG_COUNTER, seed=100 + seed, membership="binary")
     return dict(seed=seed, train=d["train"], test=d["test"], weights={k: getattr(m, k) for k in ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")})
+
+
+def fit_pairs(args):
+    """(tag, seed, train [n,2] int32, factors, epochs, loss, max_samples) -> dict(tag, seed, oracle weights): the sequential oracle on GIVEN
+    training pairs (the config-2-shaped quality tests generate their data on the GPU and hand it over), from the weights
+    `np.random.seed(seed); RankFM(...)._init_all(train)` draws, negatives drawn like the reference (uniformly over the catalogue)"""
+    import pandas as pd
+    from oracle import oracle as orc
+    from rankfm_amd import EngineOptions, RankFM
+    tag, seed, train, factors, epochs, loss, max_samples = args
+    orc.build()
+    m = RankFM(factors=factors, loss=loss, max_samples=max_samples, engine=EngineOptions(seed=100 + seed))
+    np.random.seed(seed)
+    m._init_all(pd.DataFrame(train, columns=["u", "i"]))
+    orc.fit(m.interactions, m.sample_weight, m.user_items.offsets, m.user_items.items, m.x_uf, m.x_if, m.w_i, m.w_if, m.v_u, m.v_i, m.v_uf,
+            m.v_if, m.alpha, m.beta, m.learning_rate, m.learning_schedule, m.learning_exponent, 1 if loss == "bpr" else max_samples, epochs,
+            perms=None, rng_mode=orc.RNG_COUNTER, seed=100 + seed, membership="binary")
+    return dict(tag=tag, seed=seed, weights={k: getattr(m, k) for k in ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")})

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankfm_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK = 0
 ERR_BAD_ARG, ERR_UNKNOWN_SCHEDULE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_USER_SATURATED, ERR_WORKSPACE = (
     -1, -2, -3, -4, -5, -6, -7)
@@ -39,12 +39,12 @@ class FitConfig(C.Structure):
         ("plan_token", C.c_int64),
         ("tune_segment_rows", C.c_int32), ("tune_stripe_window", C.c_int32), ("tune_stripe_rows", C.c_int32),
         ("tune_hot_publications", C.c_int32), ("tune_feature_waves", C.c_int32), ("tune_table_producers", C.c_int32),
-        ("sampler", C.c_int32), ("tune_reserved", C.c_int32 * 1),
+        ("sampler", C.c_int32), ("tune_table_every", C.c_int32),
     ]
 
 
 #: names of the geometry overrides of rfm_fit_config (0 = automatic); EngineOptions.tune / DeviceSession(tune=...) carry them
-TUNE_FIELDS = ("segment_rows", "stripe_window", "stripe_rows", "hot_publications", "feature_waves", "table_producers")
+TUNE_FIELDS = ("segment_rows", "stripe_window", "stripe_rows", "hot_publications", "feature_waves", "table_producers", "table_every")
 
 
 def tune_kwargs(tune):
@@ -78,11 +78,13 @@ class FitReport(C.Structure):
         ("workgroups", C.c_int32), ("groups_per_workgroup", C.c_int32), ("working_groups", C.c_int64),
         ("units_per_launch", C.c_int64), ("n_units", C.c_int64), ("stripe_rows", C.c_int32), ("stripe_window", C.c_int32),
         ("segment_rows", C.c_int32), ("table_producers", C.c_int32), ("table_steps", C.c_int64), ("feat_diag", C.c_int64 * 8),
+        ("table_overlap_us", C.c_int64), ("table_span_us", C.c_int64 * 2),
     ]
 
     def geometry(self):
         """launch geometry as a dict (rankfm_amd.order mirrors the engine's negative draws from it)"""
-        return dict(self._geometry(), feat_diag=[int(x) for x in self.feat_diag])
+        return dict(self._geometry(), feat_diag=[int(x) for x in self.feat_diag], table_overlap_us=int(self.table_overlap_us),
+                    table_span_us=[int(x) for x in self.table_span_us])
 
     def _geometry(self):
         return {k: int(getattr(self, k)) for k in ("workgroups", "groups_per_workgroup", "working_groups", "units_per_launch",

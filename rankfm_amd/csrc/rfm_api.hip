@@ -193,6 +193,7 @@ struct Workspace {
     float *w_pad;                     // [n_items * kBiasStride] item biases, one 64-byte line each (SgdArgs::w_stride)
     float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: zero between launches
     unsigned int *feat_flags;     // [kFeatFlagWords] producer / trainer hand-shake of the features kernel (zero between launches)
+    unsigned long long *feat_clock;   // [4] wall-clock ticks of the last launch's tables kernel (begin, end) and row-loop kernel (begin, end)
     unsigned int *tickets;        // [epochs, windows_per_epoch, kTicketWords] segment ticket heads, one set per launch
     int64_t windows_per_epoch;
     size_t bytes;
@@ -243,6 +244,7 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.sumsq = (double *)(p + o);                 o += align_up(sizeof(double) * 6 * epochs);
     w.nonfinite = (unsigned int *)(p + o);       o += align_up(sizeof(unsigned int) * epochs);
     w.error_flags = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int) * 16);
+    w.feat_clock = (unsigned long long *)(p + o);    o += align_up(sizeof(unsigned long long) * 4);      // (read back with the results: keep behind error_flags)
     w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
     w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
     w.feat_flags = (unsigned int *)(p + o);      o += align_up(sizeof(unsigned int) * kFeatFlagWords);
@@ -273,7 +275,7 @@ static int validate(const rfm_fit_config *c) {
     if (c->tune_segment_rows < 0 || c->tune_segment_rows > kSegmentRows || c->tune_stripe_window < 0 || c->tune_stripe_window > 4096 ||
         c->tune_stripe_rows < -1 || c->tune_stripe_rows > 4096 || c->tune_hot_publications < 0 || c->tune_hot_publications > 65536 ||
         c->tune_feature_waves < 0 || c->tune_feature_waves > 16 || c->tune_table_producers < 0 || c->tune_table_producers > kFeatMaxProducers ||
-        c->tune_reserved[0] ||
+        c->tune_table_every < 0 ||
         (c->sampler != RFM_SAMPLER_UNIFORM && c->sampler != RFM_SAMPLER_STRIPES))
         return RFM_ERR_BAD_ARG;
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
@@ -283,6 +285,22 @@ static int validate(const rfm_fit_config *c) {
 }
 
 static int g_sm_count = 0;
+
+// The second stream of the features path: the table trainer's kernel runs beside the row-loop kernel of the caller's stream
+// (launch_segments, rfm_sgd_inst.inc).  One per device, created on first use, never destroyed (process lifetime).
+FeatSide *feat_side() {
+    static FeatSide sides[64];
+    static bool made[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!made[dev]) {
+        if (hipStreamCreateWithFlags(&sides[dev].stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&sides[dev].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&sides[dev].join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        made[dev] = true;
+    }
+    return &sides[dev];
+}
 
 static int device_ok() {
     int dev = 0;
@@ -645,6 +663,10 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     while (feat_waves > 2 && sizeof(float) * (feat_table_floats(cfg) + 8 + (size_t)feat_waves * (64 / shape->group) *
                                               (5 + 2 * (size_t)shape->group * shape->kpl + cfg->n_user_features + cfg->n_item_features)) > kLdsBytes)
         feat_waves /= 2;
+    // (the tables kernel keeps `feat_waves`; the pipelined row loop runs 12 wavefronts per workgroup -- three per SIMD, 168 registers:
+    //  at 16 it has 128 and spills a third of its working set, rfm_sgd.hpp -- unless the caller overrides)
+    const int table_waves = feat_waves;
+    if (use_segments && feat && feat_fast && cfg->tune_feature_waves == 0 && !single_group) feat_waves = std::min(feat_waves, 12);
     const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : ((use_hot || use_stripes) ? 16 : 4));   // see sgd_segments_kernel
     // stripe geometry: as many rows as the LDS left by the hot-row accumulators holds (at most 256: more rows mean longer
     // windows for the same combining), and a window in which a stripe row receives ~8 updates (groups x window / rows)
@@ -673,6 +695,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         // weights that are stale by up to that many steps, and Hogwild only tracks sequential SGD while that window is
         // a small fraction of the data (DESIGN.md "staleness").
         int64_t cap = (int64_t)(g_sm_count > 0 ? g_sm_count : 256) * 16 / waves_per_block;
+        // (feature launches: ONE workgroup per CU whatever its size -- the 12-wavefront row loop takes three wavefronts per SIMD and no
+        //  second workgroup fits beside it; the trainer, its producers and the row loops must all be resident)
+        if (use_segments && feat) cap = std::min<int64_t>(cap, g_sm_count > 0 ? g_sm_count : 256);
         const int64_t window = (N / 128 + groups_per_block - 1) / groups_per_block;
         if (window < cap) cap = window;
         // ... and keep conflicts sparse: with g interactions in flight an update meets ~2g/I concurrent updates of its two
@@ -703,6 +728,18 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             // producers than the launch's room leaves beside one trainer and one row-loop workgroup
             n_producers = (int)std::max<int64_t>(1, std::min<int64_t>(n_producers, room - 2));
             if (grid + 1 + n_producers > room) grid = (int)std::max<int64_t>(1, room - 1 - n_producers);
+            // The tables kernel and the row-loop kernel are two launches, and the hardware deals the workgroups of EACH launch round
+            // the XCDs (workgroup b of a launch -> XCD b % 8, observed; MI355X_MICROARCH.md): with 4 + 252 workgroups on 256 CUs the
+            // XCDs 0 - 3 are handed 33 one-per-CU workgroups for their 32 CUs, the trainer's own among them -- measured, the two
+            // kernels then ran one AFTER the other (overlap 0.1 of 4.5 ms, the tables trained before the rows).  A chip-filling row
+            // loop therefore leaves every XCD as many CUs free as the tables kernel puts there (248 = 8 x 31 beside 1 + 3).
+            // Placement is not contractual: if it changes, the kernels overlap less -- slower, still correct (fixed quota).
+            const int sms = g_sm_count > 0 ? g_sm_count : 256;
+            constexpr int kXcds = 8;
+            if (sms % kXcds == 0 && grid + 1 + n_producers > sms - kXcds) {
+                const int per_xcd = sms / kXcds - (1 + n_producers + kXcds - 1) / kXcds;
+                grid = std::max(1, std::min(grid, per_xcd * kXcds));
+            }
             grid += 1 + n_producers;
         }
     }
@@ -840,9 +877,26 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.launch_index = 0;
         a.stripe_cover = stripe_rows > 0 ? std::min(1.0f, (float)grid * (float)stripe_rows / (float)cfg->n_items) : 0.0f;
         a.block_threads = waves_per_block * 64;
+        a.table_threads = table_waves * 64;
         a.feat_ring = ws.feat_ring; a.feat_flags = ws.feat_flags; a.n_producers = n_producers; a.feat_frozen = feat_frozen ? 1 : 0;
         a.tickets = nullptr;
         a.damp_positive_only = (cfg->debug_flags & 256) ? 1 : 0;
+        a.feat_clock = ws.feat_clock;
+        a.table_quota = 0;
+        // table trainer: steps to apply in a launch of `n_units` segments beside `rowloop_wgs` row-loop workgroups.  A row-loop workgroup
+        // walks about as many rows per second as the trainer applies steps (profiles/r03_notes.md section 7), so a trainer that works
+        // flat out for the length of the launch gets through rows / workgroups of them; measured on config 4's share with the split
+        // kernels: 5.8 steps/us against 1450 rows/us of 252 x 48 row groups, i.e. every 250th row in equal time.  The quota is that
+        // pace with a margin of a third (the trainer should finish BEFORE the row loops: it is launched beside them and the epoch waits for both): every (1.8 x row groups / 64)-th
+        // row -- 335 on the full chip, 22 in the opening launch -- or the caller's `tune_table_every`.
+        auto quota_of = [&](int64_t n_units_launch, int rowloop_wgs) -> int64_t {
+            const double rows = (double)N * (double)n_units_launch / (double)std::max<int64_t>(1, units);
+            // (in units of 64 row groups -- sixteen wavefronts -- which is what the measurement was made with)
+            double rowloop_groups = (double)rowloop_wgs * (double)(waves_per_block * groups_per_wave);
+            if (max_groups > 0) rowloop_groups = std::min(rowloop_groups, (double)max_groups);
+            const double every = cfg->tune_table_every > 0 ? (double)cfg->tune_table_every : std::max(1.0, 1.8 * rowloop_groups / 64.0);
+            return (int64_t)(rows / every);
+        };
         // ticket heads of launch `w` of this epoch (dynamic segment order; debug_flags bit 7 keeps the static stride)
         const bool use_tickets = use_segments && !use_stripes && !single_group && !(cfg->debug_flags & 128);
         auto tickets_of = [&](int w) -> unsigned int * {
@@ -897,6 +951,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             a.pos_end = u_begin + head_units;
             a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * head_rowloops ? 1 : 0;
             a.tickets = tickets_of((int)a.launch_index);
+            a.table_quota = quota_of(a.pos_end - a.pos_begin, head_rowloops);
             launch(a, 1 + n_producers + head_rowloops, stream);
             a.hot_direct = saved_direct;
         }
@@ -905,6 +960,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
             a.tickets = tickets_of(window);
+            if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers);
             launch(a, grid, stream);
         }
         if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);
@@ -936,8 +992,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     std::vector<unsigned long long> h_draws(E);
     std::vector<unsigned int> h_nonfinite(E);
     unsigned int h_err[16] = {0};
-    // ll | draws | sumsq | nonfinite | error_flags are laid out back to back: one copy, one synchronisation
-    const size_t res_bytes = (size_t)((const char *)(ws.error_flags + 16) - (const char *)ws.ll);
+    // ll | draws | sumsq | nonfinite | error_flags | feat_clock are laid out back to back: one copy, one synchronisation
+    const size_t res_bytes = (size_t)((const char *)(ws.feat_clock + 4) - (const char *)ws.ll);
     std::vector<char> h_res(res_bytes);
     RFM_HIP(hipMemcpyAsync(h_res.data(), ws.ll, res_bytes, hipMemcpyDeviceToHost, stream));
     RFM_HIP(hipStreamSynchronize(stream));
@@ -992,6 +1048,16 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->table_producers = n_producers;
         rep->table_steps = (int64_t)h_err[2];
         for (int k = 0; k < 8; ++k) rep->feat_diag[k] = (int64_t)h_err[4 + k];
+        rep->table_overlap_us = -1;
+        rep->table_span_us[0] = rep->table_span_us[1] = 0;
+        if (n_producers > 0) {      // (wall_clock64 counts at 100 MHz)
+            unsigned long long c[4];
+            memcpy(c, at(ws.feat_clock), sizeof c);
+            const long long lo = (long long)std::max(c[0], c[2]), hi = (long long)std::min(c[1], c[3]);
+            rep->table_overlap_us = c[0] && c[2] ? std::max<long long>(0, hi - lo) / 100 : 0;
+            rep->table_span_us[0] = (int64_t)(c[1] - c[0]) / 100;
+            rep->table_span_us[1] = (int64_t)(c[3] - c[2]) / 100;
+        }
         rep->plan_token = serial || b->perms ? 0 : (use_segments ? (n_segments | ((int64_t)(use_hot ? n_hot : 0) << 40) | ((int64_t)seg_rows << 48)) : kRowsPlan);
     }
     return status;

@@ -73,7 +73,8 @@ struct SgdArgs {
     float feat_scale;                           // scale for the dense feature tables (every row touches them)
     int32_t single_group;                       // debug: only group 0 of wavefront 0 works (sequential Hogwild kernel)
     int64_t max_groups;                         // row groups allowed to work (the concurrency cap can be below one workgroup)
-    int32_t block_threads;                      // workgroup size of the features kernel
+    int32_t block_threads;                      // workgroup size of the features row-loop kernel
+    int32_t table_threads;                      // workgroup size of the tables kernel (trainer + producers)
     // hot positive items (segments kernel, HOT instantiation): pos_scale[i] >= 2 encodes slot = int(v / 2) - 1 and
     // scale = v - 2 (slot + 1).  A workgroup accumulates its updates of slot s in LDS and publishes them with one set of
     // atomics every hot_period[s] touches (DESIGN.md "hot rows").
@@ -106,6 +107,10 @@ struct SgdArgs {
     // a ticket counter instead of striding the order with the number of groups (SegmentTickets below); nullptr = static stride
     unsigned int *tickets;                      // the launch's counter of order positions handed out, zero at launch
     int32_t damp_positive_only;                 // experiments: the round-3 rule (an item's scale applies to its step as the POSITIVE item only)
+    // features: the table trainer applies EXACTLY table_quota staged steps per launch (rounded up to whole batches) -- a number the host
+    // derives from the launch's rows and geometry, not from when the row loops happen to finish (feat_tables_kernel)
+    int64_t table_quota;
+    unsigned long long *feat_clock;             // [4] wall-clock ticks: tables kernel begin | end | row-loop kernel begin | end (diagnostics)
 };
 constexpr int kTicketWords = 16;                // one counter per launch, on a 64-byte line of its own
 constexpr int kHotBins = 16;
@@ -1449,7 +1454,7 @@ constexpr int kFeatReady = 0;                                  // [2 * producers
 constexpr int kFeatConsumed = 2 * kFeatMaxProducers;           // [2 * producers] batches the trainer has taken out of each slot
 constexpr int kFeatStop = 4 * kFeatMaxProducers;               // the regular workgroups are done
 constexpr int kFeatExited = kFeatStop + 1;                     // producers that have left
-constexpr int kFeatDone = kFeatStop + 2;                       // regular workgroups that have finished
+constexpr int kFeatDone = kFeatStop + 2;                       // (unused since the trainer works to a fixed quota)
 constexpr int kFeatFlagWords = kFeatStop + 4;
 constexpr unsigned kFeatSpinLimit = 1u << 23;                  // polls (~0.5 us each) before a waiting workgroup gives up: seconds
 
@@ -1519,13 +1524,13 @@ __device__ __forceinline__ void project_dense(float xr0, float xr1, int n, const
     const int gid = threadIdx.x / G, gpb = blockDim.x / G;                                                                                \
     const int n_slot = 1 + 2 * F + a.n_uf + a.n_if;                  /* staged step of one interaction (RowStep::stage) */                \
     const size_t batch_floats = (size_t)gpb * n_slot;                                                                                     \
-    const int n_regular = (int)gridDim.x - (trains ? 1 + NP : 0);                                                                         \
+    const int n_regular = (int)gridDim.x;                            /* (row-loop kernels: every workgroup walks rows) */                 \
     (void)lane; (void)wave; (void)n_waves; (void)sub; (void)gid; (void)flags; (void)batch_floats; (void)n_regular; (void)lds_tables; (void)table_ptr;
 
 // The roles of the features kernel other than the pipelined row loop are separate (non-inlined) functions: each gets a register
 // allocation of its own, so that the trainer's batch in flight or the generic step's feature vectors do not cost the row loop spills.
 template <int G, int KPL>
-__device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, lds_float *lds, lds_int *s_stop_p) {
+__device__ __forceinline__ void feat_table_trainer(const SgdArgs &a, lds_float *lds, lds_int *s_stop_p) {
     RFM_FEAT_LOCALS
     // natural layout of the tables: [P, F] | [Q, F] | [Q]
     for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
@@ -1572,11 +1577,10 @@ __device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, ld
     }
     const bool prefetch_ok = (size_t)gpb * NSL < 0xFFFFu;    // (else every dword of a batch takes the direct path below)
     unsigned applied = 0;
-    // A floor under the number of steps applied per launch -- one batch, or every 512th row of the launch -- so that a launch
-    // too short for the trainer's pace (small problems: the row loops are done before the second batch arrives) still trains
-    // its tables; the trainer then outlasts the row loops by a few batches.  Large launches apply far more than this (config
-    // 4: every ~240th row) and stop with the row loops, i.e. their step count depends on timing.
-    const unsigned quota = (unsigned)fmax((double)gpb, (double)a.n_rows * (double)(a.pos_end - a.pos_begin) / fmax(1.0, (double)a.n_segments) / 512.0);
+    // The trainer applies a FIXED number of staged steps per launch: the host's quota (rows of the launch / the pace a trainer keeps
+    // beside that many row-loop workgroups, rfm_api.hip), in whole batches, at least one.  It does not look at the row loops: the
+    // step count -- and with it the tables a given launch geometry produces -- no longer depends on timing.
+    const unsigned quota = (unsigned)(((a.table_quota > (int64_t)gpb ? a.table_quota : (int64_t)gpb) + gpb - 1) / gpb) * (unsigned)gpb;
     bool staged = false;                                      // LDS holds a batch that has not been applied yet
     unsigned flag_next = 0;                                   // (thread 0) the ready counter of the next batch, loaded ahead
     auto slot_of = [&](unsigned q, int &p, unsigned &par, unsigned &m) {
@@ -1596,13 +1600,9 @@ __device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, ld
         unsigned par, m;
         slot_of(q, p, par, m);
         if (threadIdx.x == 0) {
-            int stop = 0;
-            // (the row loops' end is looked at every 16th batch and whenever the trainer has to wait: the producers stay ahead of
-            // it, so without the periodic look it would never stop)
-            if ((q & 15u) == 0u && applied >= quota && __hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) stop = 1;
+            int stop = applied >= quota ? 1 : 0;
             const unsigned long long t0 = wall_clock64();
             for (unsigned spin = 0; !stop && (NP == 0 || flag_next < m + 1u); ++spin) {
-                if (applied >= quota && __hip_atomic_load(flags + kFeatDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= (unsigned)n_regular) { stop = 1; break; }
                 if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }      // (never observed: a hang guard)
                 __builtin_amdgcn_s_sleep(4);
                 if (NP > 0) flag_next = __hip_atomic_load(flags + kFeatReady + 2 * p + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1720,6 +1720,8 @@ __device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, ld
         t_seg[3] += wall_clock64() - tD;
     }
     if (threadIdx.x == 0) {
+        a.feat_clock[0] = t_begin;
+        a.feat_clock[1] = wall_clock64();
         if (applied) atomicAdd(a.error_flags + 2, applied);      // staged steps applied (rfm_fit_report.table_steps)
         atomicAdd(a.error_flags + 4, (unsigned)(t_wait / 100));
         atomicAdd(a.error_flags + 5, (unsigned)((wall_clock64() - t_begin) / 100));
@@ -1735,7 +1737,7 @@ __device__ __attribute__((noinline)) void feat_table_trainer(const SgdArgs a, ld
 }
 
 template <int G, int KPL, bool WARPB>
-__device__ __attribute__((noinline)) void feat_step_producer(const SgdArgs a, lds_float *lds, lds_int *s_stop_p) {
+__device__ __forceinline__ void feat_step_producer(const SgdArgs &a, lds_float *lds, lds_int *s_stop_p) {
     RFM_FEAT_LOCALS
     for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
     lds_float *stage = lds + n_tab;
@@ -1809,8 +1811,7 @@ __device__ __attribute__((noinline)) void feat_step_producer(const SgdArgs a, ld
 template <int G, int KPL, bool FRESH, bool WARPB>
 __device__ __forceinline__ void feat_generic_rows(const SgdArgs &a, lds_float *lds) {
     RFM_FEAT_LOCALS
-    const int first_regular = trains ? 1 + NP : 0;
-    const int64_t group = a.single_group ? (int64_t)threadIdx.x / G : ((int64_t)blockIdx.x - first_regular) * gpb + threadIdx.x / G;
+    const int64_t group = a.single_group ? (int64_t)threadIdx.x / G : (int64_t)blockIdx.x * gpb + threadIdx.x / G;
     int64_t n_groups = a.single_group ? gpb : (int64_t)n_regular * gpb;
     if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
     double ll_acc = 0.0;
@@ -1826,6 +1827,7 @@ __device__ __forceinline__ void feat_generic_rows(const SgdArgs &a, lds_float *l
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
     // ---- generic row loop (WARP, wide feature vectors, other row-group shapes; one group alone: both rows and tables) -----------
+    if (threadIdx.x == 0 && blockIdx.x == 0) a.feat_clock[2] = wall_clock64();
     for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
     __syncthreads();
     typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 0> Reg;
@@ -1870,31 +1872,46 @@ __device__ __forceinline__ void feat_generic_rows(const SgdArgs &a, lds_float *l
             }
         }
     }
-    if (trains) {
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + kFeatDone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
     if (train_here) {             // the one group trained the tables in its LDS: store them
         for (int k = threadIdx.x; k < n_tab; k += blockDim.x) *table_ptr(k) = lds_tables[k];
     }
     flush_counters(a, ll_acc, draw_acc);
+    if (threadIdx.x == 0) atomicMax(a.feat_clock + 3, wall_clock64());
 }
 
-template <int G, int KPL, bool FRESH, bool WARPB>
-__global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
+// The table trainer and its step producers: a kernel of their own (1 + n_producers workgroups, launched on a second stream beside the
+// row loops -- launch_segments in rfm_sgd_inst.inc).  Rounds 2-3 ran them as roles inside the row-loop kernel: non-inlined functions
+// whose register ceiling (128 at 1024 threads) and 1 KB of stack the row loop shared -- it compiled with 36 spilled VGPRs -- and whose
+// step count depended on when the row loops finished.  Here they have their own allocation, the row-loop kernels compile alone, and
+// the trainer applies a fixed quota of steps (SgdArgs::table_quota).
+template <int G, int KPL, bool WARPB>
+__global__ void __launch_bounds__(1024) feat_tables_kernel(const SgdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_dynamic[];
     lds_float *lds = (lds_float *)lds_dynamic;
     __shared__ int s_stop;
-    RFM_FEAT_LOCALS
-    if (trains && blockIdx.x <= (unsigned)NP) {
-        if (blockIdx.x == 0) feat_table_trainer<G, KPL>(a, lds, (lds_int *)&s_stop);
-        else feat_step_producer<G, KPL, WARPB>(a, lds, (lds_int *)&s_stop);
-        return;
-    }
+    if (blockIdx.x == 0) feat_table_trainer<G, KPL>(a, lds, (lds_int *)&s_stop);
+    else feat_step_producer<G, KPL, WARPB>(a, lds, (lds_int *)&s_stop);
+}
 
-    // ---- regular workgroups: the asynchronous row loop, tables read-only -------------------------------------------------------
-    const int first_regular = trains ? 1 + NP : 0;
-    const int64_t group = a.single_group ? (int64_t)threadIdx.x / G : ((int64_t)blockIdx.x - first_regular) * gpb + threadIdx.x / G;
+// the generic row loop (WARP with features, wide feature vectors, 4- / 64-lane row groups; one group alone: rows AND tables)
+template <int G, int KPL, bool FRESH, bool WARPB>
+__global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dynamic[];
+    feat_generic_rows<G, KPL, FRESH, WARPB>(a, (lds_float *)lds_dynamic);
+}
+
+// the pipelined row loop (BPR, <= 32 + 32 features, 16-lane row groups): every workgroup walks rows, the tables are a read-only
+// lane-major copy in LDS that its wavefronts keep refreshing
+// (THREADS: the largest workgroup the instantiation is launched with.  The loop wants ~176 VGPRs: at 1024 threads -- 128 registers --
+//  it spills ~50 of them, at 768 -- three wavefronts per SIMD, 168 registers -- two.)
+template <int G, int KPL, bool FRESH, int THREADS>
+__global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArgs a) {
+    constexpr bool WARPB = false;
+    extern __shared__ __attribute__((aligned(16))) float lds_dynamic[];
+    lds_float *lds = (lds_float *)lds_dynamic;
+    RFM_FEAT_LOCALS
+    const int first_regular = 0;
+    const int64_t group = a.single_group ? (int64_t)threadIdx.x / G : (int64_t)blockIdx.x * gpb + threadIdx.x / G;
     int64_t n_groups = a.single_group ? gpb : (int64_t)n_regular * gpb;
     if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
     double ll_acc = 0.0;
@@ -1909,11 +1926,11 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
     float vu[KPL], vu0[KPL];
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
+    if (threadIdx.x == 0 && blockIdx.x == 0) a.feat_clock[2] = wall_clock64();
 
-    constexpr bool FAST_SHAPE = G == 16 && !WARPB;
-    const bool fast = FAST_SHAPE && a.n_uf <= 32 && a.n_if <= 32 && (!a.single_group || a.feat_frozen);
-    if constexpr (FAST_SHAPE) {
-      if (fast) {
+    static_assert(G == 16, "the pipelined feature row loop is written for 16-lane row groups");
+    {
+      {
         // ---- the pipelined row loop (BPR, <= 32 + 32 features, 16-lane row groups) -------------------------------------------
         constexpr int FS = G * KPL;                                     // LDS row stride (rows are padded to full width)
         const int P8 = (a.n_uf + 7) & ~7, Q8 = (a.n_if + 7) & ~7;     // tables padded with zero rows to a multiple of 8
@@ -2187,21 +2204,19 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
                 if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * n_hot + k, d);
             }
         }
-        if (trains) {
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + kFeatDone, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
         flush_counters(a, ll_acc, draw_acc);
-        return;
+        if (threadIdx.x == 0) atomicMax(a.feat_clock + 3, wall_clock64());
       }
     }
-
-    feat_generic_rows<G, KPL, FRESH, WARPB>(a, lds);
 }
 
 // host-side launcher table (rfm_sgd_inst_*.hip): [0..3] rows kernel {hogwild, hogwild+feat, serial, serial+feat},
 // [4..7] segments kernel {plain, features kernel, fresh, features kernel fresh}, [8..9] segments kernel with hot-row accumulators {plain, fresh},
 // [10..13] segments kernel with negative stripes {plain, fresh, hot, hot+fresh}
 typedef void (*sgd_launch_fn)(const SgdArgs &, int grid, hipStream_t);
+
+// second stream of the features path (rfm_api.hip): the tables kernel forks off the caller's stream and joins it again
+struct FeatSide { hipStream_t stream; hipEvent_t fork, join; };
+FeatSide *feat_side();
 
 }  // namespace rfm

@@ -216,3 +216,36 @@ def make_planted_large(n_users, n_items, rank=16, seed=0, mean_degree=60.0, max_
     pairs = pairs[rng.permutation(len(pairs))]
     n_test = int(len(pairs) * holdout)
     return dict(test=np.ascontiguousarray(pairs[:n_test]), train=np.ascontiguousarray(pairs[n_test:]), user_tags=None, item_tags=None)
+
+
+def make_planted_large_device(n_users, n_items, rank=16, seed=0, mean_degree=60.0, max_degree=1000, holdout=0.25, pop_weight=0.5, device="cuda",
+                              chunk=4096):
+    """make_planted_large's score model evaluated on the GPU (torch: the 5e9 scores of a config-2-sized problem take a second instead
+    of the ten CPU-minutes a single process needs) -- test / measurement data only, a random stream of its own (torch generators seeded
+    with `seed`).  Returns dict(train [n,2] int32, test [m,2] int32) as numpy arrays."""
+    import torch
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1_000_003 * int(seed) + 17)
+    rng = np.random.default_rng([seed, 7])
+    B = torch.randn((n_items, rank), generator=g, device=dev, dtype=torch.float32)
+    pop = torch.empty(n_items, device=dev, dtype=torch.float32)
+    pop[torch.as_tensor(rng.permutation(n_items), device=dev)] = -pop_weight * torch.log(torch.arange(1, n_items + 1, device=dev, dtype=torch.float32))
+    deg = np.clip(rng.lognormal(np.log(mean_degree) - 0.5, 1.0, n_users), 10, min(max_degree, n_items // 2)).astype(np.int64)
+    users, items = [], []
+    for u0 in range(0, n_users, chunk):
+        u1 = min(u0 + chunk, n_users)
+        A = torch.randn((u1 - u0, rank), generator=g, device=dev, dtype=torch.float32)
+        S = 0.75 * (A @ B.T) + pop
+        U01 = torch.rand(S.shape, generator=g, device=dev, dtype=torch.float32).clamp_(1e-12, 1.0 - 1e-7)
+        S -= torch.log(-torch.log(U01))                                          # + Gumbel(0, 1)
+        d = torch.as_tensor(deg[u0:u1], device=dev)
+        d_max = int(d.max().item())
+        top = torch.topk(S, d_max, dim=1, sorted=True).indices                   # the d_max best of every row, best first
+        keep = torch.arange(d_max, device=dev)[None, :] < d[:, None]
+        users.append(np.repeat(np.arange(u0, u1, dtype=np.int32), deg[u0:u1]))
+        items.append(top[keep].to(torch.int32).cpu().numpy())
+    pairs = np.stack([np.concatenate(users), np.concatenate(items)], 1)
+    pairs = pairs[rng.permutation(len(pairs))]
+    n_test = int(len(pairs) * holdout)
+    return dict(test=np.ascontiguousarray(pairs[:n_test]), train=np.ascontiguousarray(pairs[n_test:]), user_tags=None, item_tags=None)

@@ -107,11 +107,15 @@ def test_config4_one_gpu_share_with_features_tracks_sequential_oracle(oracle):
     stream.  What that costs is decided in the first ~1 % of the rows, while the tables leave their initial values (the item
     biases pick up what the tables would carry: the two are degenerate, 8 active tags x the mean table row is an item bias), so
     the fit's opening rows run as a launch of their own in which the trainer sees every ~20th row (rfm_api.hip, "opening"):
-    log-likelihood within 2 %, |w_i| within 5 %, factor norms within 1 % (measured, eight runs: -0.5 ... +0.14 %, -1.95 ...
-    -4.0 % over all opening settings tried, -1.95 ... -2.15 % at the committed one, +0.1 / +0.0 %; without the opening +6.8 ...
-    +7.7 % and +20 ... +23 %: profiles/r03_notes.md section 7).  (2) The second epoch, GPU and oracle both from the GPU's
-    weights after the first: log-likelihood 2 %, every row norm 2 % (measured +0.16 %, <= 0.16 %).  The tables themselves hold
-    mostly gradient noise with a memory of ~170 steps (random tags): only their scale is checked."""
+    log-likelihood within 1.5 %, |w_i| within 2.5 %, factor norms within 1 % (measured in round 4, three runs: +0.53 ... +0.56 %,
+    +0.12 ... +0.26 %, +0.10 / -0.04 %; round 3: +0.1 % / -2 %; without the opening +6.8 ... +7.7 % and +20 ... +23 %:
+    profiles/r03_notes.md section 7).  (2) The second epoch, GPU and oracle both from the GPU's weights after the first:
+    log-likelihood 1 %, every row norm 1.5 % (measured +0.10 ... +0.13 %, <= 0.22 %).
+    Round 4: the trainer and its producers are a kernel of their own beside the row-loop kernel (two streams) and the trainer applies
+    a FIXED quota of staged steps per launch: the step count repeats exactly from run to run (asserted), the two kernels must really
+    overlap (asserted from the kernels' own clock stamps: an XCD that is handed more one-per-CU workgroups than it has CUs runs them
+    one after the other, and the tables are then trained BEFORE the rows -- first-epoch log-likelihood -1.7 %, |w_i| -11 %), and the
+    tables' norms are held to a stated tolerance instead of a factor 2.5."""
     from rankfm_amd import synthetic
     from rankfm_amd.engine import DeviceSession
     sh = synthetic.make_config_shard("C4", rank=0, world=8)
@@ -136,12 +140,23 @@ def test_config4_one_gpu_share_with_features_tracks_sequential_oracle(oracle):
           % (rep1["log_likelihood"][0] / out1["ll64"][0] - 1.0, r1, rep2["log_likelihood"][0] / out2["ll64"][0] - 1.0, r2, rep2["sgd_kernel_ms"][0],
              geo["table_producers"], geo["table_steps"], 6_250_000 / max(geo["table_steps"], 1)))
     assert geo["table_producers"] >= 1 and geo["table_steps"] > 6_250_000 / 1000      # the trainer keeps up with >= every 1000th row
-    np.testing.assert_allclose(rep1["log_likelihood"], out1["ll64"], rtol=0.02)
-    assert abs(r1["w_i"] - 1.0) <= 0.05 and abs(r1["v_u"] - 1.0) <= 0.01 and abs(r1["v_i"] - 1.0) <= 0.01, r1
-    np.testing.assert_allclose(rep2["log_likelihood"], out2["ll64"], rtol=0.02)
-    assert all(abs(r2[k] - 1.0) <= 0.02 for k in ("w_i", "v_u", "v_i")), r2
+    # the trainer works to a quota fixed by the launch geometry (round 4): the same number of staged steps in every run
+    again = DeviceSession(sh["interactions"], sh["sample_weight"], sh["csr_offsets"], sh["csr_items"], sh["x_uf"], sh["x_if"],
+                          sh["weights"], max_samples=1, seed=1492, learning_rate=lr)
+    again.run(epochs=1)
+    assert again.geometry()["table_steps"] == geo["table_steps"], (again.geometry()["table_steps"], geo["table_steps"])
+    del again
+    # and the tables kernel really runs BESIDE the row loops (two streams): most of the shorter one's time
+    assert geo["table_overlap_us"] >= 0.6 * min(geo["table_span_us"]), geo
+    np.testing.assert_allclose(rep1["log_likelihood"], out1["ll64"], rtol=0.015)
+    assert abs(r1["w_i"] - 1.0) <= 0.025 and abs(r1["v_u"] - 1.0) <= 0.01 and abs(r1["v_i"] - 1.0) <= 0.01, r1
+    np.testing.assert_allclose(rep2["log_likelihood"], out2["ll64"], rtol=0.01)
+    assert all(abs(r2[k] - 1.0) <= 0.015 for k in ("w_i", "v_u", "v_i")), r2
+    # the feature tables: |v_uf|, |v_if| within 20 % (measured 0.934 ... 0.938 / 1.118 ... 1.120 after the first epoch, 1.139 ... 1.142 /
+    # 0.931 ... 0.932 after the second, three runs: with the trainer's fixed quota they repeat to half a percent); |w_if| -- 32 numbers
+    # with a memory of ~170 steps -- within 0.6 ... 1.6 (measured 1.20 ... 1.21)
     for r in (r1, r2):
-        assert all(0.4 < r[k] < 2.5 for k in ("v_uf", "v_if", "w_if")), r
+        assert all(abs(r[k] - 1.0) <= 0.20 for k in ("v_uf", "v_if")) and 0.6 < r["w_if"] < 1.6, r
     assert all(np.isfinite(g2[k]).all() for k in g2)
 
 

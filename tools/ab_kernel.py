@@ -90,6 +90,10 @@ def main():
         print("%-40s kernel ms min %.3f median %.3f mean %.3f  -> %.0f M updates/s  LL/N %.5f  draws/N %.2f  |v_u| %.3f |v_i| %.3f |w_i| %.4f  wg %d"
               % (name, t.min(), np.median(t), t.mean(), N / np.median(t) / 1e3, last[k]["log_likelihood"][-1] / N, last[k]["n_draws"][-1] / N,
                  float(w["v_u"].norm()), float(w["v_i"].norm()), float(w["w_i"].norm()), g["workgroups"]), flush=True)
+        if g.get("table_producers", 0) > 0:
+            print("    tables: %d producers, %d staged steps over the last call (every %.0f-th row), kernels overlapped %d us (tables %d us, rows %d us)  wg size %d"
+                  % (g["table_producers"], g["table_steps"], N * len(last[k]["sgd_kernel_ms"]) / max(g["table_steps"], 1), g.get("table_overlap_us", -1),
+                     g.get("table_span_us", [0, 0])[0], g.get("table_span_us", [0, 0])[1], g["groups_per_workgroup"]), flush=True)
         if a.print_ll:
             print("    LL per epoch (from the initial weights): " + " ".join("%.1f" % x for x in lls[k]), flush=True)
 

@@ -1,8 +1,14 @@
-"""CPU: what does the engine's step damping change by itself (sequential oracle with the plan's scales vs the plain oracle), per variant"""
-import sys, time, os
+"""CPU-only analysis (oracle = test infrastructure): what does the engine's Hogwild step damping change BY ITSELF?  The sequential oracle
+with the plan's step scales applied (several rules) against the plain oracle on config 2's data, `max_samples` draws (50 = config 3),
+four epochs from the seeded initial weights, in the engine's keyed order and draws.  Result (profiles/r04_notes.md): scaling only the
+POSITIVE item's step (rounds 1-3) moves the fixed point of a hot item's bias -- all of config 3's +1.9 % log-likelihood / +8 % |w_i| --
+and only its BIAS part matters; scaling an item's step on BOTH sides of the pair leaves 0.01 % / 0.1 %.
+
+    python tools/damping_design_cpu.py [max_samples] [epochs]"""
+import os, sys, time
 import numpy as np
 import multiprocessing as mp
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc
 from rankfm_amd import synthetic, order
 orc.build()

@@ -1,6 +1,9 @@
-import sys, time
+"""CPU-only: the plain sequential oracle on config 2 / config 3 (same data, four epochs from the seeded initial weights, the engine's
+keyed order and draws, seed 1492): absolute log-likelihoods (double sum), norms and draws per update, the figures
+`tools/ab_kernel.py --print-ll --warmup 0 --epochs 4 --rounds 1` is compared with (profiles/r04_notes.md)."""
+import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc
 from rankfm_amd import synthetic, order
 import multiprocessing as mp
