@@ -222,12 +222,14 @@ def main():
     for _ in range(args.warmup):
         trainer.run_epoch(epoch)
         epoch += 1
-    kernel_ms, draws = [], 0
+    kernel_ms, shader_mhz, draws = [], [], 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rep = trainer.run_epoch(epoch)
         kernel_ms.append(float(rep["sgd_kernel_ms"][0]))
+        if sess is not None and sess.geometry():
+            shader_mhz.append(float(sess.geometry().get("shader_mhz", 0.0)))
         draws += int(rep["n_draws"][0])
         epoch += 1
     barrier()
@@ -252,13 +254,21 @@ def main():
         k_ms = float(np.mean(kernel_ms)) / launches                 # average duration of ONE SGD launch
         rows_per_launch = N / launches
         achieved = bytes_per_update * rows_per_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, when collected
+        traffic = atomic_requests = request_ceiling = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes / fabric requests per launch, when collected
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%s%s_hbm_bytes_per_launch" % (args.config, "_stripes" if args.negative_stripes else ""))
+                tj = json.load(open(tpath))
+                key = "%s%s" % (args.config, "_stripes" if args.negative_stripes else "")
+                traffic = tj.get(key + "_hbm_bytes_per_launch")
+                atomic_requests = tj.get(key + "_atomic_requests_per_launch")      # TCC_EA0_ATOMIC, all executed memory-side
+                request_ceiling = tj.get("atomic_request_ceiling_per_s")           # tools/microbench/request_rate.hip
             except Exception:
                 traffic = None
+        # run-to-run / box-to-box: the same binary differs by 10 - 25 % between boxes of one pool (profiles/r03_notes.md), so the line
+        # carries the spread over its own steps, the shader clock the launches ran at, and the kernel time scaled to a 2.4 GHz clock
+        k_all = np.array(kernel_ms) / launches
+        mhz = float(np.median(shader_mhz)) if shader_mhz and np.median(shader_mhz) > 0 else None
         if strong:
             what = ("%s: user shard %d of %d of ONE synthetic data set of %d users x %d items x %d interactions (this GPU: %d users, %d "
                     "interactions, all items)" % (args.config, 0 if world == 1 else rank, world if world > 1 else max(args.share, 1), U, I, cfg["n_interactions"], u_local, n_local))
@@ -308,12 +318,22 @@ def main():
                        "collective_backend": dist.get_backend() if world > 1 else None,
                        "merge_rule": ("curvature rule (SharedTables.set_merge_curvature), %d exchange(s) per epoch" % args.syncs_per_epoch) if world > 1 else None,
                        "sgd_launches_per_epoch": launches, "waves_per_launch": rep["waves_per_launch"],
-                       "mean_draws_per_update": mean_draws, "final_mean_ll_per_update": ll_last / N},
+                       "mean_draws_per_update": mean_draws,
+                       # WARP lines also carry the rate of sampled negatives (accepted draws, whole job)
+                       "sampled_negatives_per_s": float(draws) * world / elapsed,
+                       "final_mean_ll_per_update": ll_last / N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "peak_measured": peak_measured,
                          "frac_" + other_name: frac_other, "kernel_ms_" + other_name: k_ms_other,
-                         "kernel": "rfm::sgd_features_kernel" if (n_uf or n_if) else "rfm::sgd_segments_kernel", "kernel_ms_per_launch": k_ms,
+                         "kernel": "rfm::sgd_features_fast_kernel (+ rfm::feat_tables_kernel beside it)" if (n_uf or n_if) else "rfm::sgd_segments_kernel",
+                         "kernel_ms_per_launch": k_ms,
+                         "kernel_ms_min": float(k_all.min()), "kernel_ms_median": float(np.median(k_all)), "kernel_ms_max": float(k_all.max()),
+                         "frac_best_step": bytes_per_update * rows_per_launch / (float(k_all.min()) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "shader_mhz": mhz,
+                         "kernel_ms_median_at_2400mhz": (float(np.median(k_all)) * mhz / 2400.0) if mhz else None,
+                         "atomic_requests_per_update": (atomic_requests / rows_per_launch) if atomic_requests else None,
+                         "frac_of_request_ceiling": (atomic_requests / (k_ms * 1e-3) / request_ceiling) if atomic_requests and request_ceiling else None,
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }
         if strong_rec is not None:

@@ -189,6 +189,10 @@ typedef struct rfm_fit_report {
                                       row-loop kernel (two streams) were BOTH running; -1 = no trainer.  Near 0 = the two did not overlap
                                       (a profiler that serialises kernels, a device without room): the tables then were trained before the rows */
     int64_t table_span_us[2];      /* ... and how long each ran: tables kernel | row-loop kernel */
+    float shader_mhz;              /* shader clock the call's last SGD launch ran at (its workgroup 0's cycle counter against the 100 MHz
+                                      wall clock); 0 = not measured (serial / rows kernels).  The same binary differs by 10 - 25 % between
+                                      boxes of one pool: quote timings with this next to them */
+    int32_t reserved_report;       /* 0 */
 } rfm_fit_report;
 
 int rfm_abi_version(void);

@@ -78,13 +78,13 @@ class FitReport(C.Structure):
         ("workgroups", C.c_int32), ("groups_per_workgroup", C.c_int32), ("working_groups", C.c_int64),
         ("units_per_launch", C.c_int64), ("n_units", C.c_int64), ("stripe_rows", C.c_int32), ("stripe_window", C.c_int32),
         ("segment_rows", C.c_int32), ("table_producers", C.c_int32), ("table_steps", C.c_int64), ("feat_diag", C.c_int64 * 8),
-        ("table_overlap_us", C.c_int64), ("table_span_us", C.c_int64 * 2),
+        ("table_overlap_us", C.c_int64), ("table_span_us", C.c_int64 * 2), ("shader_mhz", C.c_float), ("reserved_report", C.c_int32),
     ]
 
     def geometry(self):
         """launch geometry as a dict (rankfm_amd.order mirrors the engine's negative draws from it)"""
         return dict(self._geometry(), feat_diag=[int(x) for x in self.feat_diag], table_overlap_us=int(self.table_overlap_us),
-                    table_span_us=[int(x) for x in self.table_span_us])
+                    table_span_us=[int(x) for x in self.table_span_us], shader_mhz=float(self.shader_mhz))
 
     def _geometry(self):
         return {k: int(getattr(self, k)) for k in ("workgroups", "groups_per_workgroup", "working_groups", "units_per_launch",

@@ -194,6 +194,7 @@ struct Workspace {
     float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: zero between launches
     unsigned int *feat_flags;     // [kFeatFlagWords] producer / trainer hand-shake of the features kernel (zero between launches)
     unsigned long long *feat_clock;   // [4] wall-clock ticks of the last launch's tables kernel (begin, end) and row-loop kernel (begin, end)
+    unsigned long long *sclk;         // [4] SgdArgs::sclk of the last launch
     unsigned int *tickets;        // [epochs, windows_per_epoch, kTicketWords] segment ticket heads, one set per launch
     int64_t windows_per_epoch;
     size_t bytes;
@@ -245,6 +246,7 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.nonfinite = (unsigned int *)(p + o);       o += align_up(sizeof(unsigned int) * epochs);
     w.error_flags = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int) * 16);
     w.feat_clock = (unsigned long long *)(p + o);    o += align_up(sizeof(unsigned long long) * 4);      // (read back with the results: keep behind error_flags)
+    w.sclk = (unsigned long long *)(p + o);          o += align_up(sizeof(unsigned long long) * 4);      // (likewise)
     w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
     w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
     w.feat_flags = (unsigned int *)(p + o);      o += align_up(sizeof(unsigned int) * kFeatFlagWords);
@@ -882,6 +884,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.tickets = nullptr;
         a.damp_positive_only = (cfg->debug_flags & 256) ? 1 : 0;
         a.feat_clock = ws.feat_clock;
+        a.sclk = ws.sclk;
         a.table_quota = 0;
         // table trainer: steps to apply in a launch of `n_units` segments beside `rowloop_wgs` row-loop workgroups.  A row-loop workgroup
         // walks about as many rows per second as the trainer applies steps (profiles/r03_notes.md section 7), so a trainer that works
@@ -992,8 +995,8 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     std::vector<unsigned long long> h_draws(E);
     std::vector<unsigned int> h_nonfinite(E);
     unsigned int h_err[16] = {0};
-    // ll | draws | sumsq | nonfinite | error_flags | feat_clock are laid out back to back: one copy, one synchronisation
-    const size_t res_bytes = (size_t)((const char *)(ws.feat_clock + 4) - (const char *)ws.ll);
+    // ll | draws | sumsq | nonfinite | error_flags | feat_clock | sclk are laid out back to back: one copy, one synchronisation
+    const size_t res_bytes = (size_t)((const char *)(ws.sclk + 4) - (const char *)ws.ll);
     std::vector<char> h_res(res_bytes);
     RFM_HIP(hipMemcpyAsync(h_res.data(), ws.ll, res_bytes, hipMemcpyDeviceToHost, stream));
     RFM_HIP(hipStreamSynchronize(stream));
@@ -1048,6 +1051,11 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         rep->table_producers = n_producers;
         rep->table_steps = (int64_t)h_err[2];
         for (int k = 0; k < 8; ++k) rep->feat_diag[k] = (int64_t)h_err[4 + k];
+        {   // shader clock of the last launch: cycle counter against the 100 MHz wall clock, both stamped by workgroup 0
+            unsigned long long c[4];
+            memcpy(c, at(ws.sclk), sizeof c);
+            rep->shader_mhz = (c[1] > c[0] && c[3] > c[2]) ? (float)((double)(c[3] - c[2]) / (double)(c[1] - c[0]) * 100.0) : 0.0f;
+        }
         rep->table_overlap_us = -1;
         rep->table_span_us[0] = rep->table_span_us[1] = 0;
         if (n_producers > 0) {      // (wall_clock64 counts at 100 MHz)

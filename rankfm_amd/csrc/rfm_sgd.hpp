@@ -111,6 +111,7 @@ struct SgdArgs {
     // derives from the launch's rows and geometry, not from when the row loops happen to finish (feat_tables_kernel)
     int64_t table_quota;
     unsigned long long *feat_clock;             // [4] wall-clock ticks: tables kernel begin | end | row-loop kernel begin | end (diagnostics)
+    unsigned long long *sclk;                   // [4] workgroup 0 of the row-loop kernel: wall clock (100 MHz) at its start | end, shader cycle counter at its start | end
 };
 constexpr int kTicketWords = 16;                // one counter per launch, on a 64-byte line of its own
 constexpr int kHotBins = 16;
@@ -983,6 +984,17 @@ struct RowStep {
     }
 };
 
+// The shader clock a launch actually ran at (rfm_fit_report.shader_mhz): thread 0 of workgroup 0 -- resident from the launch's first
+// microsecond to (nearly) its last -- stamps the constant 100 MHz wall clock and the shader cycle counter when it starts and when it
+// leaves.  The same binary runs 2.9 ... 3.9 ms on different boxes of the pool (profiles/r03_notes.md): without the clock next to a
+// timing, round-to-round comparisons inside that spread are noise.
+__device__ __forceinline__ void stamp_clock(const SgdArgs &a, int which) {
+    if (a.sclk && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.sclk[which] = wall_clock64();
+        a.sclk[2 + which] = (unsigned long long)clock64();
+    }
+}
+
 // wavefront reduction of the log-likelihood / draw counters, one atomic each per wavefront
 __device__ __forceinline__ void flush_counters(const SgdArgs &a, double ll_acc, unsigned draw_acc) {
 #pragma unroll
@@ -1234,6 +1246,7 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
     double ll_acc = 0.0;
     unsigned draw_acc = 0;
     const int lane_base = lane - sub;
+    stamp_clock(a, 0);
     int64_t sp = a.pos_begin + (a.single_group ? 0 : group);      // position in the epoch's segment order
     const int64_t stride = a.single_group ? 1 : n_groups;
     bool active = sp < a.pos_end && (a.single_group ? group == 0 : group < n_groups);
@@ -1410,6 +1423,7 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
         }
     }
     flush_counters(a, ll_acc, draw_acc);
+    stamp_clock(a, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1927,6 +1941,7 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
     if (threadIdx.x == 0 && blockIdx.x == 0) a.feat_clock[2] = wall_clock64();
+    stamp_clock(a, 0);
 
     static_assert(G == 16, "the pipelined feature row loop is written for 16-lane row groups");
     {
@@ -2206,6 +2221,7 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
         }
         flush_counters(a, ll_acc, draw_acc);
         if (threadIdx.x == 0) atomicMax(a.feat_clock + 3, wall_clock64());
+        stamp_clock(a, 1);
       }
     }
 }

@@ -72,12 +72,14 @@ def test_config3_full_size_warp_tracks_sequential_oracle(oracle, c2_problem):
     epochs of training first, so that the model is past the stage where every first draw violates the margin: the compared
     epoch evaluates several candidates per update (the count is printed and checked against the oracle's).  Two comparisons of
     that epoch, from the same weights, on the engine's order and draws:
-      (a) the sequential oracle under the ENGINE'S STEP DAMPING (hot items' and heavy users' steps scaled like the plan scales
-          them, DeviceSession.step_scales): what is left is asynchronous execution alone -- log-likelihood 1 %, accepted draws
-          1.5 %, norms 1 % (measured +0.15 %, -0.23 %, <= 0.2 %);
-      (b) the reference's algorithm itself: log-likelihood 2.75 %, draws 5 %, |v_u|, |v_i| 2 %, |w_i| 4 % (measured +1.91 ... +1.93 %,
-          -3.7 %, -0.06 / -0.32 %, +2.66 % in six runs -- i.e. almost all of it is the damping, a deliberate change of the
-          optimiser that keeps the Zipf head from overshooting: DESIGN.md section 5).
+      (a) the sequential oracle under the ENGINE'S STEP DAMPING (hot items' steps -- on either side of a pair -- and heavy users'
+          steps scaled like the plan scales them, DeviceSession.step_scales): what is left is asynchronous execution alone;
+      (b) the reference's algorithm itself (rankfm/_rankfm.pyx:244-326, undamped).
+    Both: log-likelihood 1 %, accepted draws 1.5 %, |v_u|, |v_i|, |w_i| 1 %.  Round 3 needed 2.75 % / 5 % / 4 % for (b): its damping
+    scaled an item's step only when it was the POSITIVE item, which moves the fixed point of a hot item's bias (+1.9 % log-likelihood,
+    -3.7 % draws, +2.7 % |w_i| on this epoch; +2 % / +9 % over four epochs from the initial weights).  Since round 4 an item's scale
+    applies to its step on either side, the fixed point is the reference's, and four epochs from the initial weights end +0.08 %,
+    0.0 %, +0.44 % from the reference algorithm (profiles/r04_notes.md).
     Correlation of the epoch's weight updates with the oracle's > 0.8 (WARP's discrete decisions -- first violating draw,
     rank-dependent multiplier -- turn stale reads into different-but-equivalent steps)."""
     U, I, N, F, pairs, csr = c2_problem
@@ -91,8 +93,7 @@ def test_config3_full_size_warp_tracks_sequential_oracle(oracle, c2_problem):
                  rep["log_likelihood"][0] / oout["ll64"][0] - 1.0, [round(_norm_ratio(g[k], oo[k]), 4) for k in ("v_u", "v_i", "w_i")]))
     assert out["nsamp"].sum() > 1.5 * N                      # the multi-draw path is what is being compared
     _assert_epoch_tracks_oracle(w0, g, rep, od, outd, ("v_u", "v_i", "w_i"), norm_tol=0.01, ll_tol=0.01, delta_corr=0.8, draws_tol=0.015)
-    _assert_epoch_tracks_oracle(w0, g, rep, o, out, ("v_u", "v_i"), norm_tol=0.02, ll_tol=0.0275, delta_corr=0.8, draws_tol=0.05)
-    assert abs(_norm_ratio(g["w_i"], o["w_i"]) - 1.0) <= 0.04
+    _assert_epoch_tracks_oracle(w0, g, rep, o, out, ("v_u", "v_i", "w_i"), norm_tol=0.01, ll_tol=0.01, delta_corr=0.8, draws_tol=0.015)
 
 
 def test_config4_one_gpu_share_with_features_tracks_sequential_oracle(oracle):

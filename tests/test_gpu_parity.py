@@ -324,7 +324,8 @@ def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem, 
       stripes  the opt-in fast sampler, twice: (a) against the oracle on the engine's own negatives (stripe schedule mirrored by
                rankfm_amd.order) -- what asynchronous execution and the step damping change -- and (b) against the oracle with the
                REFERENCE'S sampler, which holds the stripe sampler itself to the reference's trajectory.
-    Norms within 2 %; log-likelihood (against the oracle's double sum) within 1.5 % in the first epoch and 1.0 % in the second.
+    Default: norms within 1 %, log-likelihood (against the oracle's double sum) within 1.0 % in the first epoch and 0.5 % in the second;
+    stripes: 2 %, 1.5 % / 1.0 %.
     (The log-likelihood does not see what the stripes cost in RANKING quality: tests/test_gpu_quality.py does.)"""
     from rankfm_amd import synthetic
     from rankfm_amd.engine import DeviceSession
@@ -351,8 +352,12 @@ def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem, 
     for name, (oo, oout), corr in sides:
         print("full-size config 2, %s sampler, vs the oracle with %s: LL gpu/oracle - 1 =" % (sampler, name), rep["log_likelihood"] / oout["ll64"] - 1.0,
               " norms gpu/oracle - 1 =", [float(np.linalg.norm(g[k]) / np.linalg.norm(oo[k]) - 1.0) for k in ("v_u", "v_i", "w_i")])
-        _assert_statistical_parity(g, rep, oo, oout, ll_tol=0.015, corr=corr)
-        np.testing.assert_allclose(rep["log_likelihood"][1:], oout["ll64"][1:], rtol=0.010)
+        # the default: 1.0 % / 0.5 %, norms 1 % (round 4, item damping on both sides of a pair + dynamic segment order: measured
+        # +0.39 ... +0.40 % / -0.04 %, norms +0.09 / +0.16 / +0.12 % -- the first epoch's +0.4 % is the hot head's slower start under
+        # the damping, the sequential stand-in shows +0.18 %); the frozen opt-in stripes keep round 3's 1.5 % / 1.0 % / 2 %
+        tight = sampler == "uniform"
+        _assert_statistical_parity(g, rep, oo, oout, ll_tol=0.010 if tight else 0.015, norm_tol=0.01 if tight else 0.02, corr=corr)
+        np.testing.assert_allclose(rep["log_likelihood"][1:], oout["ll64"][1:], rtol=0.005 if tight else 0.010)
 
 
 @pytest.mark.parametrize("damping, stripes", [(-1.0, False), (1e9, False), (1e9, True)])
