@@ -132,7 +132,8 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--damping", type=float, default=0.0, help="hogwild damping M (0 default, <0 off)")
     ap.add_argument("--debug-flags", type=int, default=0)
-    ap.add_argument("--syncs-per-epoch", type=int, default=1, help="item-delta exchanges per epoch (N > 1)")
+    ap.add_argument("--syncs-per-epoch", default="auto", help="item-delta exchanges per epoch (N > 1): a number, or 'auto' = the production default "
+                    "(8 per epoch during a fit's first 8 epochs, 1 afterwards: rankfm_amd.distributed.ShardedTrainer)")
     ap.add_argument("--factors", type=int, default=0, help="override the config's factor count (experiments)")
     ap.add_argument("--shape", type=int, default=0, help="experiment: 1-based index into the kernel shape table")
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
@@ -206,7 +207,7 @@ def main():
     hyper = dict(alpha=0.01, beta=0.1, learning_rate=lr, learning_schedule="constant", learning_exponent=0.25,
                  max_samples=cfg["max_samples"])
     trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
-                                        syncs_per_epoch=args.syncs_per_epoch, seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
+                                        syncs_per_epoch=(args.syncs_per_epoch if args.syncs_per_epoch == "auto" else int(args.syncs_per_epoch)), seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
                                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
                                         shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check,
                                         tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv},
@@ -316,7 +317,9 @@ def main():
                        "n_users_total": u_local * world, "n_interactions_total": n_job, "parallelism": "user-shard dp%d" % world,
                        "rccl_ranks_seen": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
                        "collective_backend": dist.get_backend() if world > 1 else None,
-                       "merge_rule": ("curvature rule (SharedTables.set_merge_curvature), %d exchange(s) per epoch" % args.syncs_per_epoch) if world > 1 else None,
+                       "merge_rule": ("curvature rule in ONE all-reduce of the bucket per exchange (SharedTables.exchange_fused); exchanges per epoch: %s%s"
+                                      % (args.syncs_per_epoch, " = 8 during a fit's first 8 epochs, 1 afterwards (the timed steps are epochs %d .. %d)"
+                                         % (args.warmup, args.warmup + args.steps - 1) if args.syncs_per_epoch == "auto" else "")) if world > 1 else None,
                        "sgd_launches_per_epoch": launches, "waves_per_launch": rep["waves_per_launch"],
                        "mean_draws_per_update": mean_draws,
                        # WARP lines also carry the rate of sampled negatives (accepted draws, whole job)

@@ -64,7 +64,14 @@ class SharedTables:
         for k in SHARED_NAMES:
             starts[k] = total
             total += (sizes[k] + 63) // 64 * 64
+        # ... and, behind the tables, what the ranks have to tell each other at an exchange BESIDES their deltas: per item the two
+        # curvature terms of the merge rule (exchange_fused), the rank's sum of |v_u|^2 and user count, and a "my slice failed"
+        # flag -- all summed by the SAME all-reduce as the deltas (start = 0 and scale = 1 over the tail: it comes back as the sum)
+        n_items = shapes["w_i"][0]
+        self._tail_at, self._tail_len = total, (2 * n_items + 3 + 63) // 64 * 64
+        total += self._tail_len
         self.flat = torch.zeros(total, dtype=torch.float32, device=device)
+        self.tail = self.flat[self._tail_at:]
         self.views = {}
         for k in SHARED_NAMES:
             v = self.flat[starts[k]:starts[k] + sizes[k]].view(shapes[k])
@@ -100,6 +107,7 @@ class SharedTables:
         scale[a:a + self._sizes["v_i"]] = torch.clamp(float(damping) / n, min=1.0 / world_size, max=1.0).repeat_interleave(F)
         a = self._starts["w_i"]
         scale[a:a + self._sizes["w_i"]] = torch.clamp(float(bias_damping) / n, min=1.0 / world_size, max=1.0)
+        scale[self._tail_at:] = 1.0
         self.merge_scale = scale if world_size > 1 else None
 
     # The curvature rule (the default from round 3's end on).  An item row that a rank steps n times in an exchange window moves
@@ -117,16 +125,28 @@ class SharedTables:
     # point of each other), c_w = 0.3 for the biases (0.25 holds everywhere, 0.12 lets them run away at learning rate 0.1).
     CURVATURE_FACTORS, CURVATURE_BIASES = 0.1, 0.3
 
-    def set_merge_curvature(self, local_item_counts, world_size, learning_rate=0.1, c_factors=None, c_biases=None):
+    def set_merge_curvature(self, local_item_counts, world_size, learning_rate=0.1, c_factors=None, c_biases=None, group=None, mean_vu2=None):
         """arm the curvature rule: `local_item_counts` [I] = this rank's updates of every item per exchange window.  The scale
-        itself is computed by refresh_merge_scale before every exchange (it needs the ranks' current mean |v_u|^2)."""
+        itself is computed at every exchange (it needs the ranks' current mean |v_u|^2): by exchange_fused inside the one all-reduce
+        (`mean_vu2` = this rank's mean |v_u|^2 now; rank 0's is what everybody starts from), or by refresh_merge_scale + two small
+        collectives (the round-3 form, kept for callers that drive the exchange themselves)."""
         self._n_local = torch.as_tensor(np.asarray(local_item_counts, dtype=np.float64), dtype=torch.float64, device=self.flat.device)
         self._curvature = (float(learning_rate), float(self.CURVATURE_FACTORS if c_factors is None else c_factors),
                            float(self.CURVATURE_BIASES if c_biases is None else c_biases))
         self._world = int(world_size)
         self.merge_scale = torch.full_like(self.flat, 1.0 / world_size) if world_size > 1 else None      # (feature tables: the average)
+        if self.merge_scale is not None:
+            self.merge_scale[self._tail_at:] = 1.0                                                       # (the tail comes back as the plain sum)
+        # exchange_fused: per-item totals over all ranks (static: summed once, here) and the mean |v_u|^2 every rank starts from
+        self._n_total = self._n_local.clone()
+        if dist.is_available() and dist.is_initialized() and world_size > 1:
+            dist.all_reduce(self._n_total, op=dist.ReduceOp.SUM, group=group)
+        m0 = torch.tensor([float(mean_vu2) if mean_vu2 is not None else 0.0], dtype=torch.float64, device=self.flat.device)
+        if dist.is_available() and dist.is_initialized() and world_size > 1:
+            dist.broadcast(m0, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        self._mean_vu2 = m0[0]
 
-    def refresh_merge_scale(self, sum_vu2, n_users, group=None, eta=None):
+    def refresh_merge_scale(self, sum_vu2, n_users, group=None, eta=None, window=1.0):
         """the curvature rule's scale for the coming exchange: `sum_vu2` / `n_users` = this rank's sum of |v_u|^2 and user count
         (two small all-reduces: the mean over all ranks, and the per-item terms); `eta` = the learning rate of the epoch just
         trained when it differs from the one the rule was armed with ('invscaling' schedule)"""
@@ -143,7 +163,7 @@ class SharedTables:
             return                       # (nobody reported its users: the scale stays what it was -- the average, initially)
         mean_vu2 = float(stat[0] / stat[1])
         log_rho = curvature_log_rho(lr, c_v, c_w, mean_vu2)
-        terms = curvature_terms(self._n_local, log_rho)                                             # [3, I]
+        terms = curvature_terms(self._n_local * window, log_rho)                                    # [3, I]
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(terms, op=dist.ReduceOp.SUM, group=group)
         sv, sb = curvature_scales(terms, log_rho, self._world)
@@ -155,7 +175,64 @@ class SharedTables:
         self.last_curvature = dict(mean_vu2=mean_vu2, kappa_factors=lr * c_v * mean_vu2, kappa_biases=lr * c_w)
 
     def begin_epoch(self):
+        self.tail.zero_()
         self.start.copy_(self.flat)
+
+    def exchange_fused(self, group, sum_vu2, n_users, failed=False, eta=None, window=1.0):
+        """The exchange step of the curvature rule as ONE collective and without a host round trip: the ranks' deltas, their
+        curvature terms, their |v_u|^2 sums and their failure flags travel in the same all-reduce of the flat bucket.
+          * rho of this exchange comes from the mean |v_u|^2 the ranks agreed on at the PREVIOUS exchange (at arming time: rank 0's,
+            broadcast with the tables) -- it moves by a few percent per exchange, and every rank must use the same value;
+          * the per-item totals N_i = sum_r n_ri are static and were summed once when the rule was armed;
+          * everything between the two fused passes over the bucket is device arithmetic on [I]-sized vectors.
+        `sum_vu2` may be a device tensor (no .item() anywhere); `window` = the share of the rule's counting period (set_merge_curvature's
+        item counts) this exchange closes -- 1 / k when the period is cut into k exchanges.  Returns the (device) sum of the ranks'
+        failure flags."""
+        lr, c_v, c_w = self._curvature
+        if eta is not None:
+            lr = float(eta)
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        n_items = self._shapes["w_i"][0]
+        t = self.tail
+        log_rho_v = torch.log1p(-torch.clamp(lr * c_v * self._mean_vu2, max=0.5))                  # device scalar (float64)
+        log_rho_w = float(np.log1p(-min(lr * c_w, 0.5)))
+        t[:n_items] = (-torch.expm1(log_rho_v * (self._n_local * window))).to(torch.float32)
+        t[n_items:2 * n_items] = (-torch.expm1(log_rho_w * (self._n_local * window))).to(torch.float32)
+        t[2 * n_items] = sum_vu2
+        t[2 * n_items + 1] = float(n_users)
+        t[2 * n_items + 2] = 1.0 if failed else 0.0
+        if failed:
+            self.flat[:self._tail_at].copy_(self.start[:self._tail_at])      # a failed slice contributes no deltas (they may be non-finite)
+        use_kernels = self.flat.is_cuda
+        if use_kernels:
+            import ctypes as C
+            from . import _hip
+            stream = C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)
+            n = self.flat.numel()
+            with torch.cuda.device(self.flat.device):
+                _hip.raise_for_status(_hip.lib().rfm_delta_begin(self.flat.data_ptr(), self.start.data_ptr(), n, stream))
+        else:
+            self.flat.sub_(self.start)
+        if world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        t_v, t_w = t[:n_items].to(torch.float64), t[n_items:2 * n_items].to(torch.float64)
+        lo = 1.0 / world
+        sv = torch.where(t_v > 0, -torch.expm1(log_rho_v * (self._n_total * window)) / torch.clamp(t_v, min=1e-30), torch.ones_like(t_v)).clamp(lo, 1.0)
+        sb = torch.where(t_w > 0, -torch.expm1(log_rho_w * (self._n_total * window)) / torch.clamp(t_w, min=1e-30), torch.ones_like(t_w)).clamp(lo, 1.0)
+        F = self._shapes["v_i"][1]
+        a = self._starts["v_i"]
+        self.merge_scale[a:a + self._sizes["v_i"]].view(n_items, F).copy_(sv.to(torch.float32)[:, None].expand(n_items, F))
+        a = self._starts["w_i"]
+        self.merge_scale[a:a + self._sizes["w_i"]] = sb.to(torch.float32)
+        if use_kernels:
+            with torch.cuda.device(self.flat.device):
+                _hip.raise_for_status(_hip.lib().rfm_delta_finish(self.flat.data_ptr(), self.start.data_ptr(), self.merge_scale.data_ptr(), 1.0, n, stream))
+        else:
+            self.flat.mul_(self.merge_scale).add_(self.start)
+        # what the ranks agreed on, for the next exchange
+        users = t[2 * n_items + 1].to(torch.float64)
+        self._mean_vu2 = torch.where(users > 0, t[2 * n_items].to(torch.float64) / torch.clamp(users, min=1.0), self._mean_vu2)
+        return t[2 * n_items + 2]
 
     def all_reduce_deltas(self, group=None, average=False):
         """the exchange step: after it every rank holds epoch_start + sum (or mean) over ranks of its epoch's deltas"""
@@ -229,27 +306,79 @@ class ShardedTrainer:
 
     def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None):
         self.shared, self.epoch_fn, self.group, self.average = shared, epoch_fn, group, average
+        # exchanges per epoch: a number, or "auto" (the default of fit_distributed / bench.py) = AUTO_EXCHANGES per epoch during a fit's
+        # first AUTO_EPOCHS epochs, one per epoch afterwards (exchanges_in_epoch).  Measured with the REAL engine in every shard
+        # (tools/merge_engine_scan.py: eight shards of a config-2-shaped planted problem on one GPU, profiles/r04_notes.md): with one
+        # exchange per epoch the merged model starts slowly -- hit_rate@10 -13.9 points after 5 epochs against one GPU on the whole
+        # data (2 / 4 / 8 exchanges per epoch: -7.4 / -2.9 / +0.2; the schedule 8, 4, 2, 1, 1: -5.0) -- and overtakes it later (+2.2
+        # after 15 epochs, +4.0 after 40: the merge is a regulariser).  Shards that train a whole epoch blind to each other while
+        # the model moves fastest drift apart (a factor model may turn its latent space freely); once it moves slowly, one exchange
+        # per epoch is enough.  Every extra exchange is one more all-reduce of the bucket (13 MB at config 2, 52 MB at config 4).
         self.syncs_per_epoch = syncs_per_epoch
         self.eta_fn = eta_fn             # epoch -> learning rate of that epoch (None: the constant the merge rule was armed with)
         # () -> (sum over this rank's users of |v_u|^2, number of users): what the curvature rule of the merge needs before
         # every exchange (SharedTables.refresh_merge_scale); None = the rank has no users
         self.user_norms_fn = user_norms_fn
 
-    def _exchange(self, epoch=None):
+    @property
+    def fused(self):
+        """the curvature rule with everything in one all-reduce (SharedTables.exchange_fused): the default of a multi-rank job"""
+        return (getattr(self.shared, "_curvature", None) is not None and self.shared.merge_scale is not None and not self.average
+                and getattr(self.shared, "_n_total", None) is not None)
+
+    AUTO_EXCHANGES, AUTO_EPOCHS = 8, 8
+
+    def exchanges_in_epoch(self, epoch):
+        if self.syncs_per_epoch == "auto":
+            return self.AUTO_EXCHANGES if int(epoch) < self.AUTO_EPOCHS else 1
+        return max(1, int(self.syncs_per_epoch))
+
+    def _exchange(self, epoch=None, err=None, window=1.0):
+        if self.fused:
+            s, n = self.user_norms_fn() if self.user_norms_fn is not None else (0.0, 0)
+            eta = self.eta_fn(epoch) if (self.eta_fn is not None and epoch is not None) else None
+            flag = self.shared.exchange_fused(self.group, s, n, failed=err is not None, eta=eta, window=window)
+            if err is not None:
+                raise err                       # (after the collective: the peers are not left waiting in it)
+            # a PEER's failure: on CPU tensors the flag is read at once; on the GPU it is copied to pinned memory behind the exchange
+            # and looked at after the next local slice, whose engine call synchronises the stream anyway (check_peers) -- no host
+            # round trip is added to the exchange
+            if flag.is_cuda:
+                if getattr(self, "_peer_flag", None) is None:
+                    self._peer_flag = torch.zeros(1, dtype=torch.float32).pin_memory()
+                self._peer_flag.copy_(flag.reshape(1), non_blocking=True)
+                self._peer_pending = True
+            elif float(flag) > 0:
+                raise RuntimeError("another rank's local epoch failed; stopping on every rank")
+            return
         if getattr(self.shared, "_curvature", None) is not None and not self.average:
             s, n = self.user_norms_fn() if self.user_norms_fn is not None else (0.0, 0)
             eta = self.eta_fn(epoch) if (self.eta_fn is not None and epoch is not None) else None
-            self.shared.refresh_merge_scale(s, n, self.group, eta=eta)
+            self.shared.refresh_merge_scale(float(s), n, self.group, eta=eta, window=window)
         self.shared.all_reduce_deltas(self.group, self.average)
 
+    def check_peers(self, synchronize=False):
+        """raise if the last fused exchange carried a peer's failure flag (GPU path; `synchronize` for the call after the LAST exchange)"""
+        if getattr(self, "_peer_pending", False):
+            if synchronize:
+                torch.cuda.synchronize(self.shared.flat.device)
+            self._peer_pending = False
+            if float(self._peer_flag[0]) > 0:
+                raise RuntimeError("another rank's local epoch failed; stopping on every rank")
+
     def _local(self, epoch, **kw):
-        """one local slice, then agree on its outcome BEFORE the next collective: a rank whose slice failed (saturated user,
-        non-finite weights, a HIP error) would otherwise leave its peers waiting in the all-reduce forever"""
+        """one local slice.  A rank whose slice failed (saturated user, non-finite weights, a HIP error) must not leave its peers
+        waiting in the all-reduce: with the fused exchange it still joins the collective -- with zero deltas and its failure flag
+        raised -- and raises afterwards (_exchange); otherwise the ranks agree on the outcome BEFORE the collective."""
         err, out = None, None
         try:
             out = self.epoch_fn(self.shared.views, epoch, **kw)
-        except Exception as e:      # noqa: BLE001 -- re-raised below, on every rank
+        except Exception as e:      # noqa: BLE001 -- re-raised, on every rank
             err = e
+        if self.fused:
+            if err is None:
+                self.check_peers()              # (the engine call above has synchronised the stream)
+            return out, err
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             flag = torch.tensor([0.0 if err is None else 1.0], device=self.shared.flat.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
@@ -257,20 +386,21 @@ class ShardedTrainer:
                 err = RuntimeError("another rank's local epoch failed; stopping on every rank")
         if err is not None:
             raise err
-        return out
+        return out, None
 
     def run_epoch(self, epoch):
         # one epoch = `syncs_per_epoch` slices of the visiting order, each followed by the delta exchange
-        if self.syncs_per_epoch <= 1:
+        n_x = self.exchanges_in_epoch(epoch)
+        if n_x <= 1:
             self.shared.begin_epoch()
-            out = self._local(epoch)
-            self._exchange(epoch)
+            out, err = self._local(epoch)
+            self._exchange(epoch, err)
             return out
         total = None
-        for k in range(self.syncs_per_epoch):
+        for k in range(n_x):
             self.shared.begin_epoch()
-            out = self._local(epoch, part=(k, self.syncs_per_epoch))
-            self._exchange(epoch)
+            out, err = self._local(epoch, part=(k, n_x))
+            self._exchange(epoch, err, window=1.0 / n_x)
             if total is None:
                 total = {key: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for key, v in out.items()}
             else:
@@ -291,11 +421,14 @@ def agree_on_merge_damping(shared, shard, group=None, merge_damping=None, syncs_
     counts = torch.bincount(torch.as_tensor(np.asarray(shard["interactions"])[:, 1].astype(np.int64)),
                             minlength=shared.views["w_i"].shape[0]).to(device=device, dtype=torch.float32)
     if merge_damping is None:
-        shared.set_merge_curvature(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), learning_rate=learning_rate)
+        v_u = np.asarray(shard.get("v_u", np.zeros((0, 1), np.float32)))
+        mean_vu2 = float((v_u.astype(np.float64) ** 2).sum() / max(len(v_u), 1))
+        # (counts per EPOCH: the share of an epoch an exchange closes is passed at the exchange, ShardedTrainer._exchange)
+        shared.set_merge_curvature(counts.cpu().numpy(), dist.get_world_size(group), learning_rate=learning_rate, group=group, mean_vu2=mean_vu2)
         return
     dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     # the damping counts updates per exchange window
-    shared.set_merge_damping(counts.cpu().numpy() / max(syncs_per_epoch, 1), dist.get_world_size(group), merge_damping,
+    shared.set_merge_damping(counts.cpu().numpy() / (1 if syncs_per_epoch == "auto" else max(int(syncs_per_epoch), 1)), dist.get_world_size(group), merge_damping,
                              learning_rate=learning_rate)
 
 
@@ -323,9 +456,9 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
     def epoch_fn(_views, epoch, part=None):
         return sess.run(epochs=1, epoch_begin=epoch, part=part)
 
-    def user_norms():
+    def user_norms():           # (a device scalar: the fused exchange never reads it on the host)
         v = sess.weights["v_u"]
-        return float((v.double() ** 2).sum().item()), int(v.shape[0])
+        return torch.linalg.vector_norm(v, dtype=torch.float64) ** 2, int(v.shape[0])
 
     def eta_of(epoch):          # rankfm/_rankfm.pyx:220-223
         lr = float(hyper.get("learning_rate", 0.1))
@@ -337,8 +470,77 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
                           eta_fn=eta_of), sess
 
 
+def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per_epoch=1, seed=1492, c_factors=None, c_biases=None, **session_kw):
+    """What `world` ranks would compute, on ONE GPU and in one process: `world` user shards, each trained by the REAL engine (its own
+    DeviceSession, its own copy of the item-side tables, the concurrency plan a rank of that size gets), merged after every exchange
+    window exactly like ShardedTrainer / SharedTables.exchange_fused merge the ranks -- curvature rule, rho from the mean |v_u|^2 of
+    the previous exchange, per-item totals -- only with the all-reduce replaced by a loop.  A development and test tool (no 8-GPU node
+    is needed to see what the merge rule does to the model when the shards are trained asynchronously); the shards run one after the
+    other, so it says nothing about time.
+    problem: dict(interactions, sample_weight, csr_offsets, csr_items, x_uf, x_if, weights); returns the merged weights (numpy)."""
+    U = len(problem["csr_offsets"]) - 1
+    w = problem["weights"]
+    bounds = shard_boundaries(problem["csr_offsets"], world)
+    trainers, sessions, counts = [], [], []
+    for r in range(world):
+        sh = take_user_shard(problem["interactions"], problem["sample_weight"], problem["csr_offsets"], problem["csr_items"], problem["x_uf"],
+                             w["v_u"], int(bounds[r]), int(bounds[r + 1]))
+        t, sess = make_device_trainer(sh, {k: w[k] for k in SHARED_NAMES}, problem["x_if"], hyper, device, seed=seed + r, **session_kw)
+        trainers.append(t)
+        sessions.append(sess)
+        counts.append(torch.bincount(torch.as_tensor(sh["interactions"][:, 1].astype(np.int64)), minlength=len(w["w_i"])).to(device=device, dtype=torch.float64))
+    ref = trainers[0].shared
+    T, n_items, F = ref._tail_at, ref._shapes["w_i"][0], ref._shapes["v_i"][1]
+    lr = float(hyper.get("learning_rate", 0.1))
+    c_v = SharedTables.CURVATURE_FACTORS if c_factors is None else c_factors
+    c_w = SharedTables.CURVATURE_BIASES if c_biases is None else c_biases
+    n_total = sum(counts)
+    v0 = sessions[0].weights["v_u"]
+    mean_vu2 = (torch.linalg.vector_norm(v0, dtype=torch.float64) ** 2 / max(v0.shape[0], 1))
+    master = ref.flat[:T].clone()
+    scale = torch.full((T,), 1.0 / world, dtype=torch.float32, device=device)
+    for e in range(epochs):
+        n_x = (ShardedTrainer.AUTO_EXCHANGES if e < ShardedTrainer.AUTO_EPOCHS else 1) if syncs_per_epoch == "auto" else max(int(syncs_per_epoch), 1)
+        for k in range(n_x):
+            log_rho_v = torch.log1p(-torch.clamp(lr * c_v * mean_vu2, max=0.5))
+            log_rho_w = float(np.log1p(-min(lr * c_w, 0.5)))
+            total = torch.zeros_like(master)
+            t_v = torch.zeros(n_items, dtype=torch.float64, device=device)
+            t_w = torch.zeros_like(t_v)
+            sum_vu2, users = 0.0, 0
+            for r in range(world):
+                tr, sess = trainers[r], sessions[r]
+                tr.shared.flat[:T].copy_(master)
+                if sess is not None:
+                    sess.run(epochs=1, epoch_begin=e, part=(k, n_x) if n_x > 1 else None)
+                    sum_vu2 = sum_vu2 + torch.linalg.vector_norm(sess.weights["v_u"], dtype=torch.float64) ** 2
+                    users += int(sess.weights["v_u"].shape[0])
+                total += tr.shared.flat[:T] - master
+                t_v += (-torch.expm1(log_rho_v * (counts[r] / n_x))).to(torch.float32).to(torch.float64)
+                t_w += (-torch.expm1(log_rho_w * (counts[r] / n_x))).to(torch.float32).to(torch.float64)
+            lo = 1.0 / world
+            sv = torch.where(t_v > 0, -torch.expm1(log_rho_v * (n_total / n_x)) / torch.clamp(t_v, min=1e-30), torch.ones_like(t_v)).clamp(lo, 1.0)
+            sb = torch.where(t_w > 0, -torch.expm1(log_rho_w * (n_total / n_x)) / torch.clamp(t_w, min=1e-30), torch.ones_like(t_w)).clamp(lo, 1.0)
+            a = ref._starts["v_i"]
+            scale[a:a + ref._sizes["v_i"]].view(n_items, F).copy_(sv.to(torch.float32)[:, None].expand(n_items, F))
+            a = ref._starts["w_i"]
+            scale[a:a + ref._sizes["w_i"]] = sb.to(torch.float32)
+            master = master + scale * total
+            mean_vu2 = sum_vu2 / max(users, 1)
+    out = {}
+    ref.flat[:T].copy_(master)
+    for name in SHARED_NAMES:
+        out[name] = ref.views[name].detach().cpu().numpy().copy()
+    v_u = np.array(w["v_u"], dtype=np.float32, copy=True)
+    for r in range(world):
+        if sessions[r] is not None:
+            v_u[int(bounds[r]):int(bounds[r + 1])] = sessions[r].weights["v_u"].detach().cpu().numpy()
+    out["v_u"] = v_u
+    return out
+
+
 def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,
-                    group=None, device=None, merge_damping=None, syncs_per_epoch=1, make_trainer=None):
+                    group=None, device=None, merge_damping=None, syncs_per_epoch="auto", make_trainer=None):
     """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
     the SAME arguments and the same numpy seed.
 
@@ -348,8 +550,9 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     complete fitted model with the reference's attribute layout.  With world size 1 this is `model.fit(...)` on the resident-session path.
 
     `merge_damping`: None = the curvature rule for scaling the summed deltas (SharedTables.set_merge_curvature: follows the model's
-    mean |v_u|^2, no constant to choose); a number M = the clamp rule min(1, M / n_i) of earlier rounds.  `syncs_per_epoch` > 1
-    exchanges the deltas several times per epoch (smaller windows: every row's steps per exchange shrink).
+    mean |v_u|^2, no constant to choose); a number M = the clamp rule min(1, M / n_i) of earlier rounds.  `syncs_per_epoch`: exchanges
+    of the item-side deltas per epoch -- "auto" (default): eight per epoch during the first eight epochs, when the model moves fastest
+    and shards that do not hear from each other drift apart, one per epoch afterwards (ShardedTrainer); a number: that many, always.
 
     `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
     CPU tests; `finish()` must return the shard's trained v_u as a numpy array.
@@ -445,6 +648,7 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
             if rank == 0:
                 print("\ntraining epoch:", e)
                 print("log likelihood (un-penalised, all ranks):", round(float(ll.item()), 2))
+    trainer.check_peers(synchronize=True)     # (a peer's failure flagged in the LAST exchange)
     # assemble the full model on every rank: item-side tables are already identical, user factors are all-gathered
     for k in SHARED_NAMES:
         getattr(model, k)[...] = trainer.shared.views[k].detach().cpu().numpy()

@@ -123,6 +123,52 @@ def test_two_gloo_ranks_exchange_item_deltas(tmp_path, oracle):
     assert np.corrcoef(w_i, o["w_i"])[0, 1] > 0.9
 
 
+def _fused_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, _, _, w = _problem()
+    rng = np.random.default_rng(10 + rank)
+    shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+    counts = rng.integers(0, 400, I).astype(np.float64) * (rng.random(I) < 0.7)
+    shared.set_merge_curvature(counts, world, learning_rate=0.1, mean_vu2=0.5 + rank)            # (rank 0's 0.5 is what everybody uses)
+    out = {}
+    for x, vu2 in enumerate((3.0 + rank, 7.0 + 2 * rank)):                                       # two exchanges: the second uses the first's mean
+        shared.begin_epoch()
+        delta = torch.as_tensor(rng.normal(0, 0.01, shared._tail_at).astype(np.float32))
+        shared.flat[:shared._tail_at] += delta
+        flag = shared.exchange_fused(None, torch.tensor(vu2 * (10 + rank), dtype=torch.float64), 10 + rank, failed=False)
+        out["flat%d" % x], out["delta%d" % x], out["flag%d" % x] = shared.flat.numpy().copy(), delta.numpy(), float(flag)
+    np.savez(os.path.join(out_dir, "fused%d.npz" % rank), counts=counts, start=SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu")).flat.numpy(), **out)
+    dist.destroy_process_group()
+
+
+def test_fused_exchange_is_the_curvature_rule_in_one_all_reduce(tmp_path):
+    """SharedTables.exchange_fused (round 4: deltas, curvature terms, |v_u|^2 sums and failure flags in ONE all-reduce of the bucket,
+    no host round trip) against the rule computed by hand from curvature_log_rho / curvature_terms / curvature_scales: the first
+    exchange uses rank 0's mean |v_u|^2 from arming time, the second the mean the ranks summed during the first."""
+    from rankfm_amd.distributed import curvature_log_rho, curvature_scales, curvature_terms
+    world = 2
+    mp.spawn(_fused_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("fused%d.npz" % k)) for k in range(world)]
+    ref = SharedTables({k: _problem()[3][k] for k in SHARED_NAMES}, torch.device("cpu"))
+    T = ref._tail_at
+    cur = r[0]["start"][:T].astype(np.float64)
+    mean = 0.5
+    for x, vu2 in enumerate(((3.0, 4.0), (7.0, 9.0))):
+        assert np.array_equal(r[0]["flat%d" % x], r[1]["flat%d" % x])                             # replicas agree bit for bit
+        log_rho = curvature_log_rho(0.1, SharedTables.CURVATURE_FACTORS, SharedTables.CURVATURE_BIASES, mean)
+        sv, sb = curvature_scales(sum(curvature_terms(r[k]["counts"], log_rho) for k in range(world)), log_rho, world)
+        scale = np.full(T, 1.0 / world)
+        a = ref._starts["v_i"]; scale[a:a + ref._sizes["v_i"]] = np.repeat(sv.numpy(), F)
+        a = ref._starts["w_i"]; scale[a:a + ref._sizes["w_i"]] = sb.numpy()
+        cur = cur + scale * (r[0]["delta%d" % x].astype(np.float64) + r[1]["delta%d" % x])
+        np.testing.assert_allclose(r[0]["flat%d" % x][:T], cur, rtol=0, atol=2e-6)
+        assert r[0]["flag%d" % x] == 0.0
+        mean = (vu2[0] * 10 + vu2[1] * 11) / 21.0                                                 # what the ranks agreed on for the next exchange
+        cur = r[0]["flat%d" % x][:T].astype(np.float64)
+
+
 def test_shared_tables_bucket_layout():
     _, _, _, w = _problem()
     s = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
