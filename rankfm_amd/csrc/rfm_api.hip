@@ -883,6 +883,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         a.feat_ring = ws.feat_ring; a.feat_flags = ws.feat_flags; a.n_producers = n_producers; a.feat_frozen = feat_frozen ? 1 : 0;
         a.tickets = nullptr;
         a.damp_positive_only = (cfg->debug_flags & 256) ? 1 : 0;
+        a.warp_rows = (cfg->debug_flags & 512) ? 1 : 0;
         a.feat_clock = ws.feat_clock;
         a.sclk = ws.sclk;
         a.table_quota = 0;
