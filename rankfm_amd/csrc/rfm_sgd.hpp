@@ -1443,7 +1443,10 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
 // Same draws (keyed by CSR position and attempt), same order inside a row, same update: the one-group mode is the sequential
 // algorithm like sgd_segments_kernel's, and the Hogwild tests of configs 3 and 5 are the parity check.
 // ---------------------------------------------------------------------------------------------
-template <int G, int KPL, bool FRESH, bool HOT>
+// FULL: the factor rows fill the lanes (F == G * KPL: 64 or 128 factors, ...): no per-dword bounds predicate anywhere -- the kernel is
+// bound by its vector instructions (PMC: the SIMDs' vector ALUs are ~80 % busy on config 3), and every predicate is a compare, an
+// exec-mask save and a branch around a load.
+template <int G, int KPL, bool FRESH, bool HOT, bool FULL>
 __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArgs a) {
     static_assert(G == 16, "the WARP state machine is written for 16-lane row groups");
     constexpr int NC = KPL >= 8 ? 2 : 4;                    // item rows a group gathers per iteration
@@ -1453,7 +1456,8 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     int64_t n_groups = ((int64_t)gridDim.x * blockDim.x) / G;
     if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
-    const int F = a.n_factors;
+    const int F = FULL ? G * KPL : a.n_factors;
+    auto ok = [&](int kk) { return FULL || sub + G * kk < F; };
     extern __shared__ __attribute__((aligned(16))) float lds_tables[];
     lds_float *lds = (lds_float *)lds_tables;
     typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, true, false> Step;       // draws, membership test, fixed-point hot sums
@@ -1544,7 +1548,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
             const uint32_t seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
-                vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                vu0[k] = ok(k) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
                 vu[k] = vu0[k];
             }
 #pragma unroll
@@ -1582,18 +1586,21 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                 skip[q] = step.member(lo, hi, c[q]);      // (rankfm/_rankfm.pyx:250-253: a drawn item of the user's own is drawn again)
             }
         }
+        // (a slot with nothing to examine still gathers a row -- item 0's -- and ignores it: an unconditional load is cheaper than
+        //  the branch around a conditional one, and the kernel is not bound by its requests)
         float vc[NC][KPL];
         float wsc = 0.0f, ssc = 1.0f;                       // lane q of the group: bias and step scale of slot q's item
+        int32_t mine = 0;                                   // ... and the item itself
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
+            const int32_t cq = skip[q] ? 0 : c[q];
+            const float *row = a.v_i + (size_t)cq * F + sub;
 #pragma unroll
-            for (int k = 0; k < KPL; ++k)
-                vc[q][k] = (!skip[q] && sub + G * k < F) ? load_f32<FRESH>(a.v_i + (size_t)c[q] * F + sub + G * k) : 0.0f;
-            if (sub == q && !skip[q]) {
-                wsc = load_f32<FRESH>(a.w_i + (size_t)c[q] * a.w_stride);
-                if (a.pos_scale) ssc = a.scale_in_pad ? a.w_i[(size_t)c[q] * a.w_stride + 1] : a.pos_scale[c[q]];
-            }
+            for (int k = 0; k < KPL; ++k) vc[q][k] = ok(k) ? load_f32<FRESH>(row + G * k) : 0.0f;
+            mine = sub == q ? cq : mine;
         }
+        wsc = load_f32<FRESH>(a.w_i + (size_t)mine * a.w_stride);
+        if (a.pos_scale) ssc = a.scale_in_pad ? a.w_i[(size_t)mine * a.w_stride + 1] : a.pos_scale[mine];
         // ---- examine, in draw order ------------------------------------------------------------------------------------------
         float part[NC];
 #pragma unroll
@@ -1626,7 +1633,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                             pp = 0.0f;
 #pragma unroll
                             for (int k = 0; k < KPL; ++k) {
-                                if (sub + G * k < F) vi[k] += (float)step.hot_acc[slot * F + sub + G * k] * step.kHotUnit;
+                                if (ok(k)) vi[k] += (float)step.hot_acc[slot * F + sub + G * k] * step.kHotUnit;
                                 pp += vu[k] * vi[k];
                             }
                             wi += (float)step.hot_accw[slot] * step.kHotUnit;
@@ -1643,9 +1650,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                 if (pu < min_pu || j < 0) {                                        // :259-261 (j < 0: keep a valid index under NaN)
                     if (pu < min_pu) min_pu = pu;
                     j = c[q]; wj = wq;
-                    float sc = sq;
-                    if (sc >= 2.0f) sc -= 2.0f * floorf(sc * 0.5f);
-                    neg_scale_j = a.pos_scale ? sc : 1.0f;
+                    neg_scale_j = sq;                                              // (raw: decoded when the row is finished)
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) vj[k] = vc[q][k];
                 }
@@ -1671,7 +1676,8 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
             const float g = sw * multiplier;
             const float eta = a.eta, reg_a = a.reg_a;
             const float eta_u = eta * step.user_scale, eta_i = eta * pos_scale_i;
-            const float eta_j = a.damp_positive_only ? eta : eta * neg_scale_j;
+            if (neg_scale_j >= 2.0f) neg_scale_j -= 2.0f * floorf(neg_scale_j * 0.5f);      // (a hot item's entry carries its slot above the scale)
+            const float eta_j = (a.damp_positive_only || !a.pos_scale) ? eta : eta * neg_scale_j;
             float d_i[KPL], d_j[KPL];
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
@@ -1689,14 +1695,14 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                 if (slot >= 0) {
 #pragma unroll
                     for (int k = 0; k < KPL; ++k)
-                        if (sub + G * k < F) step.hot_add(step.hot_acc + slot * F + sub + G * k, d_i[k]);
+                        if (ok(k)) step.hot_add(step.hot_acc + slot * F + sub + G * k, d_i[k]);
                     if (sub == 0) step.hot_add(step.hot_accw + slot, dwi);
                     hot_done = true;
                     // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it (a keyed coin)
                     if (__umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)l_period[slot]) == 0u) {
 #pragma unroll
                         for (int k = 0; k < KPL; ++k) {
-                            if (sub + G * k >= F) continue;
+                            if (!ok(k)) continue;
                             const float d = step.hot_take(step.hot_acc + slot * F + sub + G * k);
                             if (d != 0.0f)
                                 atomic_add_f32(a.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
@@ -1712,12 +1718,12 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
             if (!hot_done) {
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
-                    if (sub + G * k < F) atomic_add_f32(a.v_i + (size_t)i * F + sub + G * k, d_i[k]);
+                    if (ok(k)) atomic_add_f32(a.v_i + (size_t)i * F + sub + G * k, d_i[k]);
                 if (sub == 0) atomic_add_f32(a.w_i + (size_t)i * a.w_stride, dwi);
             }
 #pragma unroll
             for (int k = 0; k < KPL; ++k)
-                if (sub + G * k < F) atomic_add_f32(a.v_i + (size_t)j * F + sub + G * k, d_j[k]);
+                if (ok(k)) atomic_add_f32(a.v_i + (size_t)j * F + sub + G * k, d_j[k]);
             if (sub == 0) atomic_add_f32(a.w_i + (size_t)j * a.w_stride, dwj);
             // (one group alone is a sequential program: the next row must read what this one wrote)
             if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
@@ -1725,7 +1731,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                 // one write-back per segment; other segments of a heavy user may be in flight, so add the delta
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
-                    if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                    if (ok(k)) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
                 if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                 have = false;
                 if (dynamic) {
