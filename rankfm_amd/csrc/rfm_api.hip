@@ -283,6 +283,8 @@ static int validate(const rfm_fit_config *c) {
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
     if (c->rng == RFM_RNG_MT19937 && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;   // one serial stream
     if (!pick_shape(c->n_factors)) return RFM_ERR_UNSUPPORTED;
+    // (a library built without the opt-in stripe sampler, RFM_NO_STRIPES)
+    if (c->sampler == RFM_SAMPLER_STRIPES && !pick_shape(c->n_factors)->table()[10]) return RFM_ERR_UNSUPPORTED;
     return RFM_OK;
 }
 
