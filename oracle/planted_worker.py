@@ -25,17 +25,24 @@ def fit_planted(args):
 
 
 def fit_pairs(args):
-    """(tag, seed, train [n,2] int32, factors, epochs, loss, max_samples) -> dict(tag, seed, oracle weights): the sequential oracle on GIVEN
+    """(tag, seed, train [n,2] int32, factors, epochs, loss, max_samples[, user_tags, item_tags, learning_rate]) -> dict(tag, seed, oracle
+    weights): the sequential oracle on GIVEN
     training pairs (the config-2-shaped quality tests generate their data on the GPU and hand it over), from the weights
     `np.random.seed(seed); RankFM(...)._init_all(train)` draws, negatives drawn like the reference (uniformly over the catalogue)"""
     import pandas as pd
     from oracle import oracle as orc
     from rankfm_amd import EngineOptions, RankFM
-    tag, seed, train, factors, epochs, loss, max_samples = args
+    tag, seed, train, factors, epochs, loss, max_samples = args[:7]
+    user_tags, item_tags, lr = (args[7], args[8], args[9]) if len(args) > 7 else (None, None, 0.1)
     orc.build()
-    m = RankFM(factors=factors, loss=loss, max_samples=max_samples, engine=EngineOptions(seed=100 + seed))
+    m = RankFM(factors=factors, loss=loss, max_samples=max_samples, learning_rate=lr, engine=EngineOptions(seed=100 + seed))
     np.random.seed(seed)
-    m._init_all(pd.DataFrame(train, columns=["u", "i"]))
+    uf = itf = None
+    if user_tags is not None:      # (feature rows for exactly the users / items of the training data)
+        us, its = np.unique(train[:, 0]), np.unique(train[:, 1])
+        uf = pd.concat([pd.DataFrame({"u": us}), pd.DataFrame(user_tags[us])], axis=1)
+        itf = pd.concat([pd.DataFrame({"i": its}), pd.DataFrame(item_tags[its])], axis=1)
+    m._init_all(pd.DataFrame(train, columns=["u", "i"]), uf, itf)
     orc.fit(m.interactions, m.sample_weight, m.user_items.offsets, m.user_items.items, m.x_uf, m.x_if, m.w_i, m.w_if, m.v_u, m.v_i, m.v_uf,
             m.v_if, m.alpha, m.beta, m.learning_rate, m.learning_schedule, m.learning_exponent, 1 if loss == "bpr" else max_samples, epochs,
             perms=None, rng_mode=orc.RNG_COUNTER, seed=100 + seed, membership="binary")

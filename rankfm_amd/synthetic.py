@@ -219,10 +219,11 @@ def make_planted_large(n_users, n_items, rank=16, seed=0, mean_degree=60.0, max_
 
 
 def make_planted_large_device(n_users, n_items, rank=16, seed=0, mean_degree=60.0, max_degree=1000, holdout=0.25, pop_weight=0.5, device="cuda",
-                              chunk=4096):
+                              chunk=4096, n_tags=0):
     """make_planted_large's score model evaluated on the GPU (torch: the 5e9 scores of a config-2-sized problem take a second instead
     of the ten CPU-minutes a single process needs) -- test / measurement data only, a random stream of its own (torch generators seeded
-    with `seed`).  Returns dict(train [n,2] int32, test [m,2] int32) as numpy arrays."""
+    with `seed`).  Returns dict(train [n,2] int32, test [m,2] int32, user_tags / item_tags [*, n_tags] float32 | None) as numpy arrays;
+    the pairs do not depend on `n_tags`."""
     import torch
     dev = torch.device(device)
     g = torch.Generator(device=dev)
@@ -232,10 +233,12 @@ def make_planted_large_device(n_users, n_items, rank=16, seed=0, mean_degree=60.
     pop = torch.empty(n_items, device=dev, dtype=torch.float32)
     pop[torch.as_tensor(rng.permutation(n_items), device=dev)] = -pop_weight * torch.log(torch.arange(1, n_items + 1, device=dev, dtype=torch.float32))
     deg = np.clip(rng.lognormal(np.log(mean_degree) - 0.5, 1.0, n_users), 10, min(max_degree, n_items // 2)).astype(np.int64)
-    users, items = [], []
+    users, items, user_tags = [], [], []
     for u0 in range(0, n_users, chunk):
         u1 = min(u0 + chunk, n_users)
         A = torch.randn((u1 - u0, rank), generator=g, device=dev, dtype=torch.float32)
+        if n_tags:
+            user_tags.append((A[:, :n_tags] > 0).to(torch.float32).cpu().numpy())
         S = 0.75 * (A @ B.T) + pop
         U01 = torch.rand(S.shape, generator=g, device=dev, dtype=torch.float32).clamp_(1e-12, 1.0 - 1e-7)
         S -= torch.log(-torch.log(U01))                                          # + Gumbel(0, 1)
@@ -248,4 +251,8 @@ def make_planted_large_device(n_users, n_items, rank=16, seed=0, mean_degree=60.
     pairs = np.stack([np.concatenate(users), np.concatenate(items)], 1)
     pairs = pairs[rng.permutation(len(pairs))]
     n_test = int(len(pairs) * holdout)
-    return dict(test=np.ascontiguousarray(pairs[:n_test]), train=np.ascontiguousarray(pairs[n_test:]), user_tags=None, item_tags=None)
+    out = dict(test=np.ascontiguousarray(pairs[:n_test]), train=np.ascontiguousarray(pairs[n_test:]), user_tags=None, item_tags=None)
+    if n_tags:      # binary tags that carry signal: the signs of the first planted dimensions (like make_planted)
+        out["user_tags"] = np.concatenate(user_tags)
+        out["item_tags"] = (B[:, :n_tags] > 0).to(torch.float32).cpu().numpy()
+    return out

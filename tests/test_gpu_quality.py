@@ -124,7 +124,12 @@ def test_default_sampler_holds_the_quality_bar_at_a_chip_filling_size_and_the_st
 
 # ---- the quality bar AT BASELINE config 2's shape: 100,000 users x 50,000 items, ~4.5 M training rows --------------
 C2_SHAPE = dict(U=100_000, I=50_000, E=5, SEEDS=5)
-C2_VARIANTS = {"bpr_k32": ("bpr", 32, 1), "bpr_k64": ("bpr", 64, 1), "warp_k32": ("warp", 32, 50)}
+C2_VARIANTS = {"bpr_k32": ("bpr", 32, 1), "bpr_k64": ("bpr", 64, 1), "warp_k32": ("warp", 32, 50),
+               # config 4's kind of model at this size: 8 + 8 binary user / item tags that carry signal, learning rate 0.05 and ten epochs
+               # (at the default 0.1 the REFERENCE ALGORITHM goes non-finite on tag features -- here as on config 4's, BASELINE.md
+               # section 5 -- and at 0.03 five epochs learn too little to rank) -- the features kernels; three seeds
+               "bpr_k32_tags": ("bpr", 32, 1)}
+C2_TAGS, C2_TAG_SEEDS, C2_TAG_LR, C2_TAG_EPOCHS = 8, 3, 0.05, 10
 
 
 @pytest.fixture(scope="module")
@@ -135,10 +140,17 @@ def c2_shape_jobs():
     import multiprocessing as mp
     from oracle.planted_worker import fit_pairs
     from rankfm_amd import synthetic
-    data = {seed: synthetic.make_planted_large_device(C2_SHAPE["U"], C2_SHAPE["I"], seed=seed) for seed in range(C2_SHAPE["SEEDS"])}
+    data = {seed: synthetic.make_planted_large_device(C2_SHAPE["U"], C2_SHAPE["I"], seed=seed, n_tags=C2_TAGS) for seed in range(C2_SHAPE["SEEDS"])}
     pool = mp.get_context("spawn").Pool(len(C2_VARIANTS) * C2_SHAPE["SEEDS"])
-    pending = {(tag, seed): pool.apply_async(fit_pairs, ((tag, seed, data[seed]["train"], F, C2_SHAPE["E"], loss, ms),))
-               for tag, (loss, F, ms) in C2_VARIANTS.items() for seed in data}
+    pending = {}
+    for tag, (loss, F, ms) in C2_VARIANTS.items():
+        for seed in data:
+            if tag.endswith("_tags"):
+                if seed < C2_TAG_SEEDS:      # (the oracle with features is ~3x the work: three seeds)
+                    pending[(tag, seed)] = pool.apply_async(fit_pairs, ((tag, seed, data[seed]["train"], F, C2_TAG_EPOCHS, loss, ms,
+                                                                         data[seed]["user_tags"], data[seed]["item_tags"], C2_TAG_LR),))
+            else:
+                pending[(tag, seed)] = pool.apply_async(fit_pairs, ((tag, seed, data[seed]["train"], F, C2_SHAPE["E"], loss, ms),))
     yield data, pending
     pool.terminate()
 
@@ -147,24 +159,35 @@ def c2_shape_jobs():
 def test_default_engine_holds_the_quality_bar_at_config2_shape(c2_shape_jobs, tag):
     """hit_rate@10 of the production default (uniform sampler, item damping, dynamic segment order) within 1.0 point of the sequential
     oracle with the reference's sampler (rankfm/_rankfm.pyx:250-253, evaluation.py:9-33), mean over FIVE seeds, at config 2's shape,
-    for BPR at k = 32 and k = 64 and for WARP (max_samples 50, config 3's loss) at k = 32; |v_u|, |v_i| within 2 %, |w_i| within 4 %."""
+    for BPR at k = 32 and k = 64, for WARP (max_samples 50, config 3's loss) at k = 32, and for a BPR model with 8 + 8 user / item tags
+    (config 4's kind of model: the features kernels, three seeds); |v_u|, |v_i| within 2 %, |w_i| within 4 %."""
     from rankfm_amd import EngineOptions, RankFM, evaluation
     data, pending = c2_shape_jobs
     loss, F, ms = C2_VARIANTS[tag]
     hits = {"oracle": [], "default": []}
     norms = {"oracle": [], "default": []}
+    tags = tag.endswith("_tags")
+    lr = C2_TAG_LR if tags else 0.1
     for seed, d in data.items():
+        if tags and seed >= C2_TAG_SEEDS:
+            continue
         train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
-        m = RankFM(factors=F, loss=loss, max_samples=ms, engine=EngineOptions(seed=100 + seed))
+        uf = itf = None
+        if tags:      # (feature rows for exactly the users / items of the training data, as the reference demands: rankfm/rankfm.py:181-211)
+            us, its = np.unique(d["train"][:, 0]), np.unique(d["train"][:, 1])
+            uf = pd.concat([pd.DataFrame({"u": us}), pd.DataFrame(d["user_tags"][us])], axis=1)
+            itf = pd.concat([pd.DataFrame({"i": its}), pd.DataFrame(d["item_tags"][its])], axis=1)
+        m = RankFM(factors=F, loss=loss, max_samples=ms, learning_rate=lr, engine=EngineOptions(seed=100 + seed))
         np.random.seed(seed)
-        m.fit(train, epochs=C2_SHAPE["E"])
+        m.fit(train, uf, itf, epochs=C2_TAG_EPOCHS if tags else C2_SHAPE["E"])
         assert m.last_fit_report["geometry"]["stripe_rows"] == 0
+        assert (m.last_fit_report["geometry"]["table_producers"] > 0) == tags      # (the features kernels ran iff there are features)
         hits["default"].append(evaluation.hit_rate(m, test, k=10))
         norms["default"].append([np.linalg.norm(m.v_u), np.linalg.norm(m.v_i), np.linalg.norm(m.w_i)])
         job = pending[(tag, seed)].get(timeout=1500)
-        o = RankFM(factors=F, loss=loss, max_samples=ms, engine=EngineOptions(seed=100 + seed))
+        o = RankFM(factors=F, loss=loss, max_samples=ms, learning_rate=lr, engine=EngineOptions(seed=100 + seed))
         np.random.seed(seed)
-        o._init_all(train)
+        o._init_all(train, uf, itf)
         for k, v in job["weights"].items():
             setattr(o, k, np.ascontiguousarray(v))
         o.is_fit = True
@@ -174,7 +197,7 @@ def test_default_engine_holds_the_quality_bar_at_config2_shape(c2_shape_jobs, ta
     got, want = np.mean(norms["default"], axis=0), np.mean(norms["oracle"], axis=0)
     print("config-2 shape %s: hit_rate@10 %s means %s  norms / oracle - 1 %s" % (tag, {k: np.round(v, 4).tolist() for k, v in hits.items()}, mean,
                                                                              np.round(got / want - 1.0, 4).tolist()))
-    assert mean["oracle"] > 0.3                                              # the task is learnable (a popularity ranking scores ~0.1 here)
+    assert mean["oracle"] > 0.25                                             # the task is learnable (a popularity ranking scores ~0.1 here)
     assert abs(mean["default"] - mean["oracle"]) <= 0.010, mean
     np.testing.assert_allclose(got[:2], want[:2], rtol=0.02)
     np.testing.assert_allclose(got[2], want[2], rtol=0.04)
