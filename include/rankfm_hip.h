@@ -225,6 +225,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *dev, void *
  * arrays back into the caller's memory.  This is the 1:1 replacement of the reference call site. */
 int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *host, int device, rfm_fit_report *report);
 
+/* rfm_fit_host keeps its device staging allocation between calls (one per device, grown on demand); this releases them all. */
+void rfm_release_cache(void);
+
 /* ---- `_predict` (rankfm/_rankfm.pyx:345-390): pairs are float32 [n,2] indexes, NaN = unknown id ---- */
 typedef struct rfm_model_view {
     int32_t n_users, n_items, n_user_features, n_item_features, n_factors;

@@ -107,7 +107,7 @@ EXPORTS = (
     "rfm_abi_version", "rfm_status_string", "rfm_last_error", "rfm_device_count", "rfm_fit_supported",
     "rfm_fit_workspace_bytes", "rfm_fit_device", "rfm_fit_host", "rfm_predict_device", "rfm_predict_host",
     "rfm_recommend_device", "rfm_recommend_workspace_bytes", "rfm_recommend_host", "rfm_similar_host", "rfm_hbm_probe",
-    "rfm_delta_begin", "rfm_delta_finish",
+    "rfm_delta_begin", "rfm_delta_finish", "rfm_release_cache",
 )
 
 _lib = None
@@ -168,6 +168,7 @@ def lib():
     L.rfm_delta_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, C.c_void_p]
     L.rfm_hbm_probe.restype = C.c_int
     L.rfm_hbm_probe.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.rfm_release_cache.restype = None
     L.rfm_similar_host.restype = C.c_int
     L.rfm_similar_host.argtypes = [C.POINTER(ModelView), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int]
     if L.rfm_abi_version() != ABI_VERSION:

@@ -475,7 +475,15 @@ size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg), ticket_windows(cfg)).bytes;
 }
 
+// `host_offsets`: the caller's HOST copy of the CSR offsets, when it has one (rfm_fit_host): the planner then cuts the user segments
+// from it instead of reading the device copy back (one 8 (U + 1)-byte transfer and one stream synchronisation less per planned call)
+static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep, const int64_t *host_offsets);
+
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
+    return fit_device_impl(cfg, b, hip_stream, rep, nullptr);
+}
+
+static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep, const int64_t *host_offsets) {
     int rc = validate(cfg);
     if (rc != RFM_OK) return rc;
     if (!b || !b->interactions || !b->sample_weight || !b->csr_offsets || !b->csr_items || !b->x_uf || !b->x_if ||
@@ -545,10 +553,14 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     int n_hot = have_plan ? (int)((cfg->plan_token >> 40) & 0xFF) : 0;
     const bool build_plan = !serial && (cfg->plan_token <= 0 || (token_plan && !have_plan));
     std::vector<int64_t> off;
+    std::vector<int> item_count;
     if (use_segments && build_plan) {
         off.resize((size_t)cfg->n_users + 1);
-        RFM_HIP(hipMemcpyAsync(off.data(), b->csr_offsets, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost, stream));
-        RFM_HIP(hipStreamSynchronize(stream));
+        if (host_offsets) memcpy(off.data(), host_offsets, sizeof(int64_t) * off.size());
+        else {
+            RFM_HIP(hipMemcpyAsync(off.data(), b->csr_offsets, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost, stream));
+            RFM_HIP(hipStreamSynchronize(stream));
+        }
         if (off[cfg->n_users] != N) use_segments = false;            // lists hold more than this call's interactions
     }
     if (use_segments && build_plan) {
@@ -570,6 +582,13 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
         RFM_HIP(hipMemsetAsync(ws.sw_max_bits, 0, sizeof(unsigned int), stream));
         sw_to_csr_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, b->sample_weight, (long long)N, b->csr_offsets,
                                                                  b->csr_items, (unsigned int *)ws.sw_csr, ws.error_flags, ws.sw_max_bits);
+        // (the item histogram of plan part 2 rides on the same synchronisation: one read-back round trip less per planned call)
+        if (!serial && damp_m > 0.0f && !one_group_flag) {
+            item_count.resize((size_t)cfg->n_items);
+            RFM_HIP(hipMemsetAsync(ws.pos_scale, 0, sizeof(float) * (size_t)cfg->n_items, stream));
+            item_count_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, (long long)N, (int *)ws.pos_scale);
+            RFM_HIP(hipMemcpyAsync(item_count.data(), ws.pos_scale, sizeof(int) * item_count.size(), hipMemcpyDeviceToHost, stream));
+        }
         unsigned int flags = 0;
         RFM_HIP(hipMemcpyAsync(&flags, ws.error_flags, sizeof flags, hipMemcpyDeviceToHost, stream));
         RFM_HIP(hipStreamSynchronize(stream));                        // also: `desc` is pageable host memory
@@ -609,8 +628,7 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     const bool damp = !serial && !single_group && damp_m > 0.0f && N > 0;
 
     // ---- plan, part 2: item popularity (positive occurrences per item), needed by the damping and by the hot-row choice
-    std::vector<int> item_count;
-    if (damp && build_plan) {
+    if (damp && build_plan && item_count.empty()) {
         item_count.resize((size_t)cfg->n_items);
         RFM_HIP(hipMemsetAsync(ws.pos_scale, 0, sizeof(float) * (size_t)cfg->n_items, stream));
         item_count_kernel<<<dim3(1024), dim3(256), 0, stream>>>(b->interactions, (long long)N, (int *)ws.pos_scale);
@@ -1074,6 +1092,23 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     return status;
 }
 
+struct HostArena { char *ptr; size_t bytes; };
+static HostArena &host_arena(int device) {
+    static HostArena arenas[64];
+    return arenas[device >= 0 && device < 64 ? device : 0];
+}
+
+void rfm_release_cache(void) {
+    int n = 0, cur = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < n && d < 64; ++d) {
+        HostArena &c = host_arena(d);
+        if (c.ptr) { (void)hipSetDevice(d); (void)hipFree(c.ptr); c.ptr = nullptr; c.bytes = 0; }
+    }
+    (void)hipSetDevice(cur);
+}
+
 int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device, rfm_fit_report *rep) {
     int rc = validate(cfg);
     if (rc != RFM_OK) return rc;
@@ -1110,15 +1145,23 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         {nullptr, &d.workspace, ws_bytes, false},
     };
     // ONE device allocation for everything (14 hipMalloc / hipFree pairs cost more than a millisecond of a 2.6 ms epoch), carved
-    // on 256-byte boundaries
+    // on 256-byte boundaries -- and KEPT between calls (per device, grown when a call needs more, released by rfm_release_cache or
+    // at process exit): the reference's call site calls `_fit` once per fit, but epoch-by-epoch callers (fit_partial loops) pay the
+    // allocation and the implicit synchronisation of hipFree every time otherwise.  Not re-entrant, like the reference's `_fit`.
     size_t total = 0;
     for (Item &it : items) total += align_up(it.bytes ? it.bytes : 16);
-    char *arena = nullptr;
-    {
-        hipError_t e = hipMalloc((void **)&arena, total);
+    HostArena &cache = host_arena(device);
+    if (cache.bytes < total) {
+        if (cache.ptr) (void)hipFree(cache.ptr);
+        cache.ptr = nullptr; cache.bytes = 0;
+        hipError_t e = hipMalloc((void **)&cache.ptr, total);
         if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+        cache.bytes = total;
     }
-    auto cleanup = [&]() { (void)hipFree(arena); };
+    char *arena = cache.ptr;
+    auto cleanup = [&]() {};
+    // (Pinning the caller's weight arrays for the call -- hipHostRegister, so that both of their copies run as direct DMA -- was
+    //  measured in round 4: 8.8 ms against 8.7 - 9.4 ms for a one-epoch config-2 call: registering 39 MB costs what it saves.)
     size_t at = 0;
     for (Item &it : items) {
         const bool keep_null = it.bytes == 0 && it.dst != (void **)&d.csr_items && it.dst != (void **)&d.interactions &&
@@ -1133,7 +1176,7 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         }
     }
     d.workspace_bytes = ws_bytes;
-    rc = rfm_fit_device(cfg, &d, nullptr, rep);
+    rc = fit_device_impl(cfg, &d, nullptr, rep, h->csr_offsets);
     // the reference mutates the weights in place; on a non-finite epoch it has done so too (rankfm/_rankfm.pyx:329)
     if (rc == RFM_OK || rc >= RFM_ERR_NONFINITE) {
         for (Item &it : items) {

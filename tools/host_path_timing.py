@@ -11,15 +11,15 @@ pairs, csr = synthetic.make_interactions(U, I, N, seed=0)
 w = synthetic.init_weights(U, I, F, seed=1492)
 sw = np.ones(N, np.float32)
 x_uf, x_if = np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32)
-for epochs in (1, 1, 5, 20):
+for epochs, flags in ((1, 0), (1, 0), (1, 0), (5, 0), (20, 0)):
     g = {k: v.copy() for k, v in w.items()}
     rep = {}
     t0 = time.perf_counter()
     _fit(pairs, sw, csr, x_uf, x_if, g["w_i"], g["w_if"], g["v_u"], g["v_i"], g["v_uf"], g["v_if"], 0.01, 0.1, 0.1, "constant", 0.25, 1,
-         epochs, False, engine=EngineOptions(seed=1), report=rep)
+         epochs, False, engine=EngineOptions(seed=1, debug_flags=flags), report=rep)
     dt = time.perf_counter() - t0
-    print("host-buffer _fit: epochs=%d  wall %.1f ms  -> %.1f M updates/s (PCIe + plan inclusive); kernel ms/epoch %s" % (
-        epochs, dt * 1e3, N * epochs / dt / 1e6, np.round(rep["sgd_kernel_ms"][:3], 2)), flush=True)
+    print("host-buffer _fit: epochs=%d%s  wall %.1f ms  -> %.1f M updates/s (PCIe + plan inclusive); kernel ms/epoch %s" % (
+        epochs, " (debug_flags %d)" % flags if flags else "", dt * 1e3, N * epochs / dt / 1e6, np.round(rep["sgd_kernel_ms"][:3], 2)), flush=True)
 
 # the floor of the boundary: the same host buffers moved by plain copies (pageable numpy memory -> HBM and the weights back), nothing else
 import torch
