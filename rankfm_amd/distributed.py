@@ -329,6 +329,8 @@ class ShardedTrainer:
     AUTO_EXCHANGES, AUTO_EPOCHS = 8, 8
 
     def exchanges_in_epoch(self, epoch):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return 1                              # (one rank: nothing to exchange, the epoch is one launch)
         if self.syncs_per_epoch == "auto":
             return self.AUTO_EXCHANGES if int(epoch) < self.AUTO_EPOCHS else 1
         return max(1, int(self.syncs_per_epoch))
