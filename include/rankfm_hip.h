@@ -111,13 +111,13 @@ typedef struct rfm_fit_config {
                                       bit 1: factor-row loads bypass the per-CU L1,
                                       bit 2: no LDS accumulation of hot item rows,
                                       bit 3: no negative stripes even when `sampler` asks for them,
-                                      bit 4: negative stripes for WARP as well (experiments; BPR only by default),
+                                      bit 4: (unused since round 4: negative stripes are BPR only),
                                       bit 5: models with features: the dense feature tables are NOT trained (no table trainer); with
                                              bit 0 the row loop of the features kernel runs on one row group -- parity tests,
                                       bit 6: models with features: no table-friendly opening launch in the fit's first epoch (experiments),
                                       bit 7: row groups stride the epoch's segment order statically instead of taking tickets (experiments),
                                       bit 8: the item damping scales an item's step only when it is the POSITIVE item, the round-3 rule (experiments),
-                                      bit 9: WARP launches run a row's whole candidate loop before the wavefront moves on, the round-3 kernel (experiments) */
+                                      bit 9: (unused) */
     int32_t epoch_part_index;      /* with epoch_parts > 1: run only part k (0-based) of each epoch's visiting order -- lets a */
     int32_t epoch_parts;           /* multi-GPU caller exchange item deltas several times per epoch; 0 or 1 = whole epochs    */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step

@@ -538,7 +538,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
     const bool one_group_flag = (cfg->debug_flags & 1) != 0;
     bool want_stripes = use_segments && !feat && cfg->sampler == RFM_SAMPLER_STRIPES && !(cfg->debug_flags & 8) &&
-                        (cfg->max_samples == 1 || (cfg->debug_flags & 16)) && cfg->n_factors == shape->group * shape->kpl &&
+                        cfg->max_samples == 1 && cfg->n_factors == shape->group * shape->kpl &&
                         (one_group_flag || (damp_m > 0.0f && N > 0));
     if (want_stripes && !one_group_flag && cfg->n_workgroups <= 0) {
         const long long cap_groups = std::min<long long>(N / 128, (long long)std::min(cfg->n_users, cfg->n_items) / 3);
@@ -661,8 +661,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     // Negative stripes (rfm_sgd.hpp, STRIPE; include/rfm_rng.h): the production path without features.  debug_flags bit 3 falls back to whole-catalogue draws with one set of atomics per negative.
     // BPR only: WARP's candidate screening inside a stripe (up to 50 draws WITH replacement from ~200 items) changes the
     // statistics of the rank estimate -- against the sequential oracle the log-likelihood moved by -5 % at a 12-row window --
-    // and the WARP instantiation gained no time from it (it is bound by its register spills, not by the candidate reads);
-    // debug_flags bit 4 switches them on for experiments.
+    // and the WARP instantiation gained no time from it (the experiment's instantiations left the tree in round 4).
     // Full factor rows only (n_factors == lanes per group x dwords per lane: 16, 32, 48, 64, 96, 128, ...): the stripe
     // instantiations carry no per-dword bounds predicate.
     // (decided before the plan was cut -- `want_stripes`, "Segment length" above -- including the size condition: launches that
@@ -903,7 +902,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         a.feat_ring = ws.feat_ring; a.feat_flags = ws.feat_flags; a.n_producers = n_producers; a.feat_frozen = feat_frozen ? 1 : 0;
         a.tickets = nullptr;
         a.damp_positive_only = (cfg->debug_flags & 256) ? 1 : 0;
-        a.warp_rows = (cfg->debug_flags & 512) ? 1 : 0;
+        a.reserved_i32 = 0;
         a.feat_clock = ws.feat_clock;
         a.sclk = ws.sclk;
         a.table_quota = 0;

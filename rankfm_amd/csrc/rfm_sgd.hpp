@@ -107,7 +107,7 @@ struct SgdArgs {
     // a ticket counter instead of striding the order with the number of groups (SegmentTickets below); nullptr = static stride
     unsigned int *tickets;                      // the launch's counter of order positions handed out, zero at launch
     int32_t damp_positive_only;                 // experiments: the round-3 rule (an item's scale applies to its step as the POSITIVE item only)
-    int32_t warp_rows;                          // experiments: WARP launches take sgd_segments_kernel (a row's candidate loop runs to its end, rounds 1-3)
+    int32_t reserved_i32;
     // features: the table trainer applies EXACTLY table_quota staged steps per launch (rounded up to whole batches) -- a number the host
     // derives from the launch's rows and geometry, not from when the row loops happen to finish (feat_tables_kernel)
     int64_t table_quota;
@@ -1875,7 +1875,8 @@ __device__ __forceinline__ void project_dense(float xr0, float xr1, int n, const
     const int n_slot = 1 + 2 * F + a.n_uf + a.n_if;                  /* staged step of one interaction (RowStep::stage) */                \
     const size_t batch_floats = (size_t)gpb * n_slot;                                                                                     \
     const int n_regular = (int)gridDim.x;                            /* (row-loop kernels: every workgroup walks rows) */                 \
-    (void)lane; (void)wave; (void)n_waves; (void)sub; (void)gid; (void)flags; (void)batch_floats; (void)n_regular; (void)lds_tables; (void)table_ptr;
+    (void)lane; (void)wave; (void)n_waves; (void)sub; (void)gid; (void)flags; (void)batch_floats; (void)n_regular; (void)lds_tables; (void)table_ptr; \
+    (void)trains; (void)NP; (void)n_tab;
 
 // The roles of the features kernel other than the pipelined row loop are separate (non-inlined) functions: each gets a register
 // allocation of its own, so that the trainer's batch in flight or the generic step's feature vectors do not cost the row loop spills.
@@ -2185,7 +2186,7 @@ __device__ __forceinline__ void feat_generic_rows(const SgdArgs &a, lds_float *l
     Reg step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     Both both(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     const bool train_here = a.single_group && !a.feat_frozen;          // one group alone trains the tables in its LDS
-    for (int iter = 0; __any(active); ++iter) {
+    while (__any(active)) {
         if (trains) {
             const int per = (n_tab + n_waves - 1) / n_waves, e0 = wave * per, e1 = e0 + per < n_tab ? e0 + per : n_tab;
             for (int k = e0 + lane; k < e1; k += 64)
@@ -2256,7 +2257,6 @@ __global__ void __launch_bounds__(1024) sgd_features_kernel(const SgdArgs a) {
 //  it spills ~50 of them, at 768 -- three wavefronts per SIMD, 168 registers -- two.)
 template <int G, int KPL, bool FRESH, int THREADS>
 __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArgs a) {
-    constexpr bool WARPB = false;
     extern __shared__ __attribute__((aligned(16))) float lds_dynamic[];
     lds_float *lds = (lds_float *)lds_dynamic;
     RFM_FEAT_LOCALS
