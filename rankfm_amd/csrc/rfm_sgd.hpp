@@ -141,6 +141,29 @@ template <int CTRL>
 __device__ __forceinline__ int32_t dpp_movi(int32_t x) {
     return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false);
 }
+// The launch's arguments re-read from the kernel-argument segment.  A kernel keeps every field of its by-value SgdArgs it ever uses
+// in scalar registers from its first instruction on; the WARP kernel, say, needs ~150 and has 102, and what does not fit is parked in
+// the lanes of a vector register -- one v_readlane (a VECTOR instruction, in a kernel bound by those) per use.  The rarely
+// executed parts of a row loop (a segment's start, a row's update, the sweeping duty) instead take a copy of the arguments through
+// a pointer the compiler cannot see through: the fields such a part uses are scalar loads when it is entered (the scalar cache
+// holds the 456-byte segment) and occupy registers only inside it.  (SgdArgs is the kernel's first and only parameter: offset 0.)
+__device__ __forceinline__ SgdArgs cold_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) SgdArgs *KernelArgPtr;
+    KernelArgPtr p = (KernelArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;                         // (only the fields the caller goes on to use are loaded)
+#else
+    return SgdArgs();                  // (the host pass of the compiler only parses device code)
+#endif
+}
+// (the frozen stripe instantiations keep the arguments they were measured with: COLD = false is a plain copy)
+template <bool COLD>
+__device__ __forceinline__ SgdArgs cold_args_if(const SgdArgs &a) {
+    if constexpr (COLD) return cold_args();
+    else return a;
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float x) {
     if constexpr (G >= 16) {
@@ -898,17 +921,18 @@ struct RowStep {
                 // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it
                 // (a keyed coin with probability 1 / period instead of a shared counter: no LDS round trip on the row's path)
                 if (__umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)a.hot_period[slot]) == 0u) {     // probability 1 / period
+                    const SgdArgs c = cold_args_if<!STRIPE>(a);
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
                         const float d = hot_take(hot_acc + slot * F + dword_f(k));
                         if (d != 0.0f)
-                            atomic_add_f32(a.hot_direct ? a.v_i + (size_t)i * F + dword_f(k)
-                                                        : a.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * a.n_hot + slot) * F + dword_f(k), d);
+                            atomic_add_f32(c.hot_direct ? a.v_i + (size_t)i * F + dword_f(k)
+                                                        : c.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * c.n_hot + slot) * F + dword_f(k), d);
                     }
                     if (sub == 0) {
                         const float d = hot_take(hot_accw + slot);
-                        if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)i * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + slot, d);
+                        if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * c.n_hot + slot, d);
                     }
                 }
             }
@@ -1339,19 +1363,22 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
             // its line stays in the sweeper's L2, and the memory-side atomics of the publishers in the other XCDs never invalidate
             // it.  profiles/r04_notes.md.)
             const int n_waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-            if (!a.hot_direct && iter % n_waves == wave)
-                for (int line = blockIdx.x; line < hot_lines(a); line += gridDim.x) hot_sweep_line(a, line);
+            if (!a.hot_direct && iter % n_waves == wave) {
+                const SgdArgs c = cold_args_if<!STRIPE>(a);                        // (the rarely executed parts read their arguments afresh: cold_args)
+                for (int line = blockIdx.x; line < hot_lines(c); line += gridDim.x) hot_sweep_line(c, line);
+            }
         }
         if (active && !have) {
-            const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
-            const int4 d = a.seg_desc[seg];
+            const SgdArgs c = cold_args_if<!STRIPE>(a);
+            const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)c.n_segments, c.seg_bits, c.epoch_key ^ 0x5bd1e995u);
+            const int4 d = c.seg_desc[seg];
             u = d.x; begin = d.y; len = d.z;
-            lo = a.csr_off[u]; hi = a.csr_off[u + 1];
+            lo = c.csr_off[u]; hi = c.csr_off[u + 1];
             len_bits = (int32_t)rfm_perm_bits((uint32_t)len);
-            seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
+            seg_key = rfm_mix32(c.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
-                vu0[k] = (STRIPE || sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                vu0[k] = (STRIPE || sub + G * k < F) ? load_f32<FRESH>(c.v_u + (size_t)u * F + sub + G * k) : 0.0f;
                 vu[k] = vu0[k];
             }
             t = 0;
@@ -1389,16 +1416,17 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
                 step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
             }
             if (++t == len) {
+                const SgdArgs c = cold_args_if<!STRIPE>(a);
                 // one write-back per segment; other segments of a heavy user may be in flight, so add the delta
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
-                    if (STRIPE || sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                    if (STRIPE || sub + G * k < F) atomic_add_f32(c.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
                 have = false;
                 bool stepped = false;
                 if constexpr (!STRIPE) {
                     if (dynamic) {
                         int64_t nxt = -1;
-                        if (sub == 0) nxt = tickets.take(a);
+                        if (sub == 0) nxt = tickets.take(c);
                         sp = __shfl(nxt, lane_base);
                         active = sp >= 0;
                         stepped = true;
@@ -1535,28 +1563,31 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
         if (!__any(active)) break;
         if constexpr (HOT) {      // bin sweeping duty (SgdArgs::hot_bins_v), as in sgd_segments_kernel
             const int n_waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-            if (!a.hot_direct && iter % (n_waves * kSweepEvery) == wave * kSweepEvery)
-                for (int line = blockIdx.x; line < hot_lines(a); line += gridDim.x) hot_sweep_line(a, line);
+            if (!a.hot_direct && iter % (n_waves * kSweepEvery) == wave * kSweepEvery) {
+                const SgdArgs c = cold_args();
+                for (int line = blockIdx.x; line < hot_lines(c); line += gridDim.x) hot_sweep_line(c, line);
+            }
         }
         if (active && !have) {
-            const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
-            const int4 d = a.seg_desc[seg];
+            const SgdArgs c = cold_args();
+            const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)c.n_segments, c.seg_bits, c.epoch_key ^ 0x5bd1e995u);
+            const int4 d = c.seg_desc[seg];
             u = d.x; len = d.z;
             const int32_t begin = d.y;
-            lo = a.csr_off[u]; hi = a.csr_off[u + 1];
+            lo = c.csr_off[u]; hi = c.csr_off[u + 1];
             const uint32_t len_bits = rfm_perm_bits((uint32_t)len);
-            const uint32_t seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
+            const uint32_t seg_key = rfm_mix32(c.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
-                vu0[k] = ok(k) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                vu0[k] = ok(k) ? load_f32<FRESH>(c.v_u + (size_t)u * F + sub + G * k) : 0.0f;
                 vu[k] = vu0[k];
             }
 #pragma unroll
             for (int k = 0; k < SEGR; ++k) {
                 const int tt = sub + G * k;
                 seg_pos[k] = tt < len ? begin + (int32_t)rfm_perm((uint32_t)tt, (uint32_t)len, len_bits, seg_key) : begin;
-                seg_item[k] = a.csr_items[seg_pos[k]];
-                seg_sw[k] = a.sw_csr[seg_pos[k]];
+                seg_item[k] = c.csr_items[seg_pos[k]];
+                seg_sw[k] = c.sw_csr[seg_pos[k]];
             }
             t = 0;
             have = true;
@@ -1668,16 +1699,17 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
             wj = wi; min_pu = 1e6f; sampled = 1; sw = 0.0f;
         }
         if (active && done) {
+            const SgdArgs c = cold_args();
             const float pu = min_pu;                                               // :267-268
-            const float multiplier = n_mult ? l_mult[sampled] : a.multiplier[sampled];   // :269 (integer division inside the log)
+            const float multiplier = n_mult ? l_mult[sampled] : c.multiplier[sampled];   // :269 (integer division inside the log)
             float log_sig, d_outer;
             sigmoid_terms(pu, log_sig, d_outer);                                   // :270, :276
             if (sub == 0) { ll_acc += (double)log_sig; draw_acc += (unsigned)sampled; }
             const float g = sw * multiplier;
-            const float eta = a.eta, reg_a = a.reg_a;
+            const float eta = c.eta, reg_a = c.reg_a;
             const float eta_u = eta * step.user_scale, eta_i = eta * pos_scale_i;
             if (neg_scale_j >= 2.0f) neg_scale_j -= 2.0f * floorf(neg_scale_j * 0.5f);      // (a hot item's entry carries its slot above the scale)
-            const float eta_j = (a.damp_positive_only || !a.pos_scale) ? eta : eta * neg_scale_j;
+            const float eta_j = (c.damp_positive_only || !a.pos_scale) ? eta : eta * neg_scale_j;
             float d_i[KPL], d_j[KPL];
 #pragma unroll
             for (int k = 0; k < KPL; ++k) {
@@ -1705,12 +1737,12 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                             if (!ok(k)) continue;
                             const float d = step.hot_take(step.hot_acc + slot * F + sub + G * k);
                             if (d != 0.0f)
-                                atomic_add_f32(a.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
-                                                            : a.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * a.n_hot + slot) * F + sub + G * k, d);
+                                atomic_add_f32(c.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
+                                                            : c.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * c.n_hot + slot) * F + sub + G * k, d);
                         }
                         if (sub == 0) {
                             const float d = step.hot_take(step.hot_accw + slot);
-                            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)i * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + slot, d);
+                            if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * c.n_hot + slot, d);
                         }
                     }
                 }
@@ -1726,22 +1758,22 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                 if (ok(k)) atomic_add_f32(a.v_i + (size_t)j * F + sub + G * k, d_j[k]);
             if (sub == 0) atomic_add_f32(a.w_i + (size_t)j * a.w_stride, dwj);
             // (one group alone is a sequential program: the next row must read what this one wrote)
-            if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            if (c.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             if (++t == len) {
                 // one write-back per segment; other segments of a heavy user may be in flight, so add the delta
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
-                    if (ok(k)) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
-                if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                    if (ok(k)) atomic_add_f32(c.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                if (c.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                 have = false;
                 if (dynamic) {
                     int64_t nxt = -1;
-                    if (sub == 0) nxt = tickets.take(a);
+                    if (sub == 0) nxt = tickets.take(c);
                     sp = __shfl(nxt, lane_base);
                     active = sp >= 0;
                 } else {
                     sp += stride;
-                    active = sp < a.pos_end;
+                    active = sp < c.pos_end;
                 }
             }
         }
@@ -2386,36 +2418,39 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
             }
             // bin sweeping duty (SgdArgs::hot_bins_v).  The lines are owned by the ROW-LOOP workgroups only: the trainer and the producers
             // never come here, and a line nobody sweeps -- the first lines are the hottest items' -- would stay unpublished all launch
-            if (n_hot > 0 && !a.hot_direct && iter % n_waves == wave)
-                for (int line = (int)blockIdx.x - first_regular; line < hot_lines(a); line += n_regular) hot_sweep_line(a, line);
+            if (n_hot > 0 && !a.hot_direct && iter % n_waves == wave) {
+                const SgdArgs c = cold_args();                           // (the rarely executed parts read their arguments afresh: cold_args)
+                for (int line = (int)blockIdx.x - first_regular; line < hot_lines(c); line += n_regular) hot_sweep_line(c, line);
+            }
             if (active && !have) {
-                const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)a.n_segments, a.seg_bits, a.epoch_key ^ 0x5bd1e995u);
-                const int4 d = a.seg_desc[seg];
+                const SgdArgs c = cold_args();
+                const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)c.n_segments, c.seg_bits, c.epoch_key ^ 0x5bd1e995u);
+                const int4 d = c.seg_desc[seg];
                 u = d.x; begin = d.y; len = d.z;
-                lo = a.csr_off[u]; hi = a.csr_off[u + 1];
+                lo = c.csr_off[u]; hi = c.csr_off[u + 1];
                 len_bits = (int32_t)rfm_perm_bits((uint32_t)len);
-                seg_key = rfm_mix32(a.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
+                seg_key = rfm_mix32(c.epoch_key ^ (seg * 0x9E3779B9u + 0x7F4A7C15u));
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) {
-                    vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_u + (size_t)u * F + sub + G * k) : 0.0f;
+                    vu0[k] = (sub + G * k < F) ? load_f32<FRESH>(c.v_u + (size_t)u * F + sub + G * k) : 0.0f;
                     vu[k] = vu0[k];
                 }
                 t = 0;
                 have = true;
                 step.load_ulist(lo, hi);
                 xu0 = xu1 = 0.0f;
-                if (a.has_uf) {
-                    const float *x = a.x_uf + (size_t)u * a.n_uf;
-                    if (sub < a.n_uf) xu0 = x[sub];
-                    if (sub + G < a.n_uf) xu1 = x[sub + G];
+                if (c.has_uf) {
+                    const float *x = c.x_uf + (size_t)u * c.n_uf;
+                    if (sub < c.n_uf) xu0 = x[sub];
+                    if (sub + G < c.n_uf) xu1 = x[sub + G];
                 }
                 // the segment's rows in visiting order, held across the lanes (row t in lane t % G, register t / G)
 #pragma unroll
                 for (int k = 0; k < SEGR; ++k) {
                     const int tt = sub + G * k;
                     seg_pos[k] = tt < len ? begin + (int32_t)rfm_perm((uint32_t)tt, (uint32_t)len, (uint32_t)len_bits, seg_key) : begin;
-                    seg_item[k] = a.csr_items[seg_pos[k]];
-                    seg_sw[k] = a.sw_csr[seg_pos[k]];
+                    seg_item[k] = c.csr_items[seg_pos[k]];
+                    seg_sw[k] = c.sw_csr[seg_pos[k]];
                 }
                 fetch_pos(__shfl(pick(seg_item, 0), lane_base), nxt);
             }
@@ -2506,34 +2541,36 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
                 }
                 // every hot_period-th toucher of a slot publishes what the workgroup has accumulated for it (a keyed coin, RowStep)
                 if (slot >= 0 && __umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)a.hot_period[slot]) == 0u) {
+                    const SgdArgs c = cold_args();
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (sub + G * k >= F) continue;
                         const float d = (float)__hip_atomic_exchange(hot_acc + slot * F + sub + G * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * hot_unit;
                         if (d != 0.0f)
-                            atomic_add_f32(a.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
-                                                        : a.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * n_hot + slot) * F + sub + G * k, d);
+                            atomic_add_f32(c.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
+                                                        : c.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * n_hot + slot) * F + sub + G * k, d);
                     }
                     if (sub == 0) {
                         const float d = (float)__hip_atomic_exchange(hot_accw + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * hot_unit;
-                        if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)i * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * n_hot + slot, d);
+                        if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * n_hot + slot, d);
                     }
                 }
                 if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next row reads what this one wrote
                 if (++t == len) {
+                    const SgdArgs c = cold_args();
 #pragma unroll
                     for (int k = 0; k < KPL; ++k)
-                        if (sub + G * k < F) atomic_add_f32(a.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
-                    if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                        if (sub + G * k < F) atomic_add_f32(c.v_u + (size_t)u * F + sub + G * k, vu[k] - vu0[k]);
+                    if (c.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
                     have = false;
                     if (dynamic) {
                         int64_t nx = -1;
-                        if (sub == 0) nx = tickets.take(a);
+                        if (sub == 0) nx = tickets.take(c);
                         sp = __shfl(nx, lane_base);
                         active = sp >= 0;
                     } else {
                         sp += stride;
-                        active = sp < a.pos_end;
+                        active = sp < c.pos_end;
                     }
                 }
             }
