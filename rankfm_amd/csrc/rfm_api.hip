@@ -910,14 +910,22 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // walks about as many rows per second as the trainer applies steps (profiles/r03_notes.md section 7), so a trainer that works
         // flat out for the length of the launch gets through rows / workgroups of them; measured on config 4's share with the split
         // kernels: 5.8 steps/us against 1450 rows/us of 252 x 48 row groups, i.e. every 250th row in equal time.  The quota is that
-        // pace with a margin of a third (the trainer should finish BEFORE the row loops: it is launched beside them and the epoch waits for both): every (1.8 x row groups / 64)-th
-        // row -- 335 on the full chip, 22 in the opening launch -- or the caller's `tune_table_every`.
-        auto quota_of = [&](int64_t n_units_launch, int rowloop_wgs) -> int64_t {
+        // pace with a wide margin: every (2.4 x row groups / 64)-th row -- 446 on the full chip; the opening launch keeps 1.8 x: every 22nd --
+        // or the caller's `tune_table_every`.  Why 2.4 and not the 1.8 of a trainer that "just finishes first": ranking quality against the
+        // sequential oracle is a HUMP in this number (profiles/r04_notes.md section 11; config-2 shape with tags, three seeds: every
+        // 250th row -3.8 points of hit_rate@10, 290th -0.4, 335th -0.3 ... -0.8 depending on the build, 400th - 450th -0.1, 600th -1.2; at
+        // config 4's shape the 450th ranks 1.6 points better than the 335th) -- a tables kernel that runs for nearly as long as the row
+        // loops beside it (0.9 of their time at the 335th row on config 4's shape) is already on the hump's steep side.  Launches that do
+        // not fill a good part of the chip (fewer than 4096 row groups) keep 1.8: their row loops are latency-bound and slow per row, the
+        // trainer is nowhere near their length, and the 3000 x 2000 feature fixture sits within 0.3 point of the REFERENCE there (2.4
+        // ranks it a full point ABOVE the reference -- outside the bar from the other side).
+        auto quota_of = [&](int64_t n_units_launch, int rowloop_wgs, double factor) -> int64_t {
             const double rows = (double)N * (double)n_units_launch / (double)std::max<int64_t>(1, units);
             // (in units of 64 row groups -- sixteen wavefronts -- which is what the measurement was made with)
             double rowloop_groups = (double)rowloop_wgs * (double)(waves_per_block * groups_per_wave);
             if (max_groups > 0) rowloop_groups = std::min(rowloop_groups, (double)max_groups);
-            const double every = cfg->tune_table_every > 0 ? (double)cfg->tune_table_every : std::max(1.0, 1.8 * rowloop_groups / 64.0);
+            if (rowloop_groups < 4096.0) factor = std::min(factor, 1.8);
+            const double every = cfg->tune_table_every > 0 ? (double)cfg->tune_table_every : std::max(1.0, factor * rowloop_groups / 64.0);
             return (int64_t)(rows / every);
         };
         // ticket heads of launch `w` of this epoch (dynamic segment order; debug_flags bit 7 keeps the static stride)
@@ -974,7 +982,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             a.pos_end = u_begin + head_units;
             a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * head_rowloops ? 1 : 0;
             a.tickets = tickets_of((int)a.launch_index);
-            a.table_quota = quota_of(a.pos_end - a.pos_begin, head_rowloops);
+            a.table_quota = quota_of(a.pos_end - a.pos_begin, head_rowloops, 1.8);
             launch(a, 1 + n_producers + head_rowloops, stream);
             a.hot_direct = saved_direct;
         }
@@ -983,7 +991,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
             a.tickets = tickets_of(window);
-            if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers);
+            if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, 2.4);
             launch(a, grid, stream);
         }
         if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);

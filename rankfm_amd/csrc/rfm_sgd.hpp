@@ -157,12 +157,10 @@ __device__ __forceinline__ SgdArgs cold_args() {
     return SgdArgs();                  // (the host pass of the compiler only parses device code)
 #endif
 }
-// (the frozen stripe instantiations keep the arguments they were measured with: COLD = false is a plain copy)
-template <bool COLD>
-__device__ __forceinline__ SgdArgs cold_args_if(const SgdArgs &a) {
-    if constexpr (COLD) return cold_args();
-    else return a;
-}
+// (the frozen stripe instantiations keep the code they were measured with: with COLD = false, `c` IS the kernel's parameter)
+#define RFM_COLD_ARGS(c, COLD)                                            \
+    const SgdArgs c##_reread_ = (COLD) ? cold_args() : SgdArgs();         \
+    const SgdArgs &c = (COLD) ? c##_reread_ : a;
 
 template <int G>
 __device__ __forceinline__ float group_sum(float x) {
@@ -921,7 +919,7 @@ struct RowStep {
                 // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it
                 // (a keyed coin with probability 1 / period instead of a shared counter: no LDS round trip on the row's path)
                 if (__umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)a.hot_period[slot]) == 0u) {     // probability 1 / period
-                    const SgdArgs c = cold_args_if<!STRIPE>(a);
+                    RFM_COLD_ARGS(c, !STRIPE)
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;
@@ -1364,12 +1362,12 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
             // it.  profiles/r04_notes.md.)
             const int n_waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
             if (!a.hot_direct && iter % n_waves == wave) {
-                const SgdArgs c = cold_args_if<!STRIPE>(a);                        // (the rarely executed parts read their arguments afresh: cold_args)
+                RFM_COLD_ARGS(c, !STRIPE)                        // (the rarely executed parts read their arguments afresh: cold_args)
                 for (int line = blockIdx.x; line < hot_lines(c); line += gridDim.x) hot_sweep_line(c, line);
             }
         }
         if (active && !have) {
-            const SgdArgs c = cold_args_if<!STRIPE>(a);
+            RFM_COLD_ARGS(c, !STRIPE)
             const uint32_t seg = rfm_perm((uint32_t)sp, (uint32_t)c.n_segments, c.seg_bits, c.epoch_key ^ 0x5bd1e995u);
             const int4 d = c.seg_desc[seg];
             u = d.x; begin = d.y; len = d.z;
@@ -1416,7 +1414,7 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
                 step(rfm_row_key(a.epoch_key, (uint32_t)pos), u, i, sw, lo, hi, vu, ll_acc, draw_acc);
             }
             if (++t == len) {
-                const SgdArgs c = cold_args_if<!STRIPE>(a);
+                RFM_COLD_ARGS(c, !STRIPE)
                 // one write-back per segment; other segments of a heavy user may be in flight, so add the delta
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)

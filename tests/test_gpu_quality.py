@@ -177,13 +177,20 @@ def test_default_engine_holds_the_quality_bar_at_config2_shape(c2_shape_jobs, ta
             us, its = np.unique(d["train"][:, 0]), np.unique(d["train"][:, 1])
             uf = pd.concat([pd.DataFrame({"u": us}), pd.DataFrame(d["user_tags"][us])], axis=1)
             itf = pd.concat([pd.DataFrame({"i": its}), pd.DataFrame(d["item_tags"][its])], axis=1)
-        m = RankFM(factors=F, loss=loss, max_samples=ms, learning_rate=lr, engine=EngineOptions(seed=100 + seed))
-        np.random.seed(seed)
-        m.fit(train, uf, itf, epochs=C2_TAG_EPOCHS if tags else C2_SHAPE["E"])
-        assert m.last_fit_report["geometry"]["stripe_rows"] == 0
-        assert (m.last_fit_report["geometry"]["table_producers"] > 0) == tags      # (the features kernels ran iff there are features)
-        hits["default"].append(evaluation.hit_rate(m, test, k=10))
-        norms["default"].append([np.linalg.norm(m.v_u), np.linalg.norm(m.v_i), np.linalg.norm(m.w_i)])
+        # (a model with tags is scored over FOUR engine seeds per data seed: its trajectory is chaotic in the engine's settings -- the same
+        #  data and weights under a slightly different table quota or build move a seed's hit rate by +-0.5 point, profiles/r04_notes.md
+        #  section 11 -- and three single runs would leave the mean +-0.3 point of that alone)
+        runs_hit, runs_norm = [], []
+        for engine_seed in ([100 + seed, 1100 + seed, 2100 + seed, 3100 + seed] if tags else [100 + seed]):
+            m = RankFM(factors=F, loss=loss, max_samples=ms, learning_rate=lr, engine=EngineOptions(seed=engine_seed))
+            np.random.seed(seed)
+            m.fit(train, uf, itf, epochs=C2_TAG_EPOCHS if tags else C2_SHAPE["E"])
+            assert m.last_fit_report["geometry"]["stripe_rows"] == 0
+            assert (m.last_fit_report["geometry"]["table_producers"] > 0) == tags      # (the features kernels ran iff there are features)
+            runs_hit.append(evaluation.hit_rate(m, test, k=10))
+            runs_norm.append([np.linalg.norm(m.v_u), np.linalg.norm(m.v_i), np.linalg.norm(m.w_i)])
+        hits["default"].append(float(np.mean(runs_hit)))
+        norms["default"].append(np.mean(runs_norm, axis=0))
         job = pending[(tag, seed)].get(timeout=1500)
         o = RankFM(factors=F, loss=loss, max_samples=ms, learning_rate=lr, engine=EngineOptions(seed=100 + seed))
         np.random.seed(seed)
