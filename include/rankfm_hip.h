@@ -137,7 +137,8 @@ typedef struct rfm_fit_config {
                                       full chip, 2 / 1 on small launches) */
     int32_t sampler;               /* RFM_SAMPLER_* (0 = the reference's uniform sampler) */
     int32_t tune_table_every;      /* features kernel: the table trainer applies rows-of-the-launch / this many staged steps per launch
-                                      (auto: 1.25 x the launch's row-loop workgroups, the pace a trainer keeps beside them; 20 in the opening launch) */
+                                      (auto: 2.4 x the launch's row groups / 64 -- every 446th row on a full chip -- on launches of at least
+                                      4096 row groups, 1.8 x on smaller ones and in the opening launch: an empirical optimum) */
 } rfm_fit_config;
 
 /* All pointers of one struct live in the same memory space: device memory for the *_device entry
