@@ -154,6 +154,10 @@ typedef struct {
      * `table_every` (0 rows = no head) -- a sequential stand-in for a slow, table-friendly opening of the first epoch */
     int32_t table_head_every;
     int64_t table_head_rows;
+    /* analysis only: after every epoch, `table_tail` further visits of randomly chosen rows (keyed by epoch and count) that update the
+     * dense feature tables ONLY -- biases and factor rows frozen -- a sequential stand-in for a table trainer that goes on after the row
+     * loops of its launch are done (tools/table_quota_standin.py).  0 = none (the reference). */
+    int64_t table_tail;
 } rfm_oracle_params;
 
 /* return codes */
@@ -214,14 +218,17 @@ static int fit_impl(const rfm_oracle_params *p,
         float log_likelihood = 0.0f;                                               /* :228 */
         double log_likelihood64 = 0.0;     /* the same sum without the float accumulator's rounding (ll64_out) */
 
-        for (int64_t r = 0; r < N; ++r) {                                          /* :230 */
-            const int64_t row = perms ? perms[(size_t)e * N + r]
+        const int64_t n_visits = N + (p->table_tail > 0 ? p->table_tail : 0);      /* (analysis option: table-only visits behind the epoch) */
+        for (int64_t r = 0; r < n_visits; ++r) {                                   /* :230 */
+            const int tail = r >= N;
+            const int64_t row = tail ? (int64_t)rfm_draw_to_item(rfm_mix32(ekey ^ (0x51ED270BU + (uint32_t)(r - N))), (uint32_t)N)
+                              : perms ? perms[(size_t)e * N + r]
                                       : (int64_t)rfm_perm((uint32_t)r, (uint32_t)N, perm_bits, ekey);
             const int u = interactions[2 * row], i = interactions[2 * row + 1];    /* :233-235 */
             const float sw = sample_weight[row];                                   /* :236 */
             const int32_t *items_u = csr_items + csr_off[u];
             const int64_t n_u = csr_off[u + 1] - csr_off[u];
-            const uint32_t rkey = rfm_row_key(ekey, (uint32_t)row);
+            const uint32_t rkey = tail ? rfm_row_key(ekey ^ 0x3C6EF372U, (uint32_t)r) : rfm_row_key(ekey, (uint32_t)row);   /* (tail visits draw negatives of their own) */
             uint32_t attempt = 0;
 
             const float ut_ui = utility(&m, u, i);                                 /* :239 */
@@ -249,17 +256,20 @@ static int fit_impl(const rfm_oracle_params *p,
             /* :269 -- C integer division inside the log (cdivision=True) */
             const float multiplier = (float)(log((double)((I - 1) / sampled)) / log((double)I));
             const double log_sig = log(1.0 / (1.0 + exp(-(double)pu)));
-            log_likelihood = (float)((double)log_likelihood + log_sig);            /* :270 */
-            log_likelihood64 += log_sig;
+            if (!tail) {
+                log_likelihood = (float)((double)log_likelihood + log_sig);        /* :270 */
+                log_likelihood64 += log_sig;
+            }
             const float d_outer = (float)(1.0 / (exp((double)pu) + 1.0));         /* :276 */
-            if (neg_out) neg_out[(size_t)e * N + r] = j;
-            if (nsamp_out) nsamp_out[(size_t)e * N + r] = sampled;
+            if (neg_out && !tail) neg_out[(size_t)e * N + r] = j;
+            if (nsamp_out && !tail) nsamp_out[(size_t)e * N + r] = sampled;
 
             /* (rfm_oracle_fit_ex: the engine's Hogwild step damping applied sequentially -- the positive item's step and
              *  the user's step are scaled, nothing else; both scales are 1 in rfm_oracle_fit) */
-            const float eta_i = pos_step ? eta * pos_step[i] : eta, eta_u = user_step ? eta * user_step[u] : eta;
-            const float eta_iw = pos_step_bias ? eta * pos_step_bias[i] : eta_i;   /* (the bias of the positive item may be damped on its own) */
-            const float eta_j = neg_step ? eta * neg_step[j] : eta;                /* (the engine scales an item's step whichever side it is on) */
+            const float eta_row = tail ? 0.0f : eta;                               /* (a tail visit leaves biases and factor rows alone) */
+            const float eta_i = pos_step ? eta_row * pos_step[i] : eta_row, eta_u = user_step ? eta_row * user_step[u] : eta_row;
+            const float eta_iw = pos_step_bias ? eta_row * pos_step_bias[i] : eta_i;   /* (the bias of the positive item may be damped on its own) */
+            const float eta_j = neg_step ? eta_row * neg_step[j] : eta_row;            /* (the engine scales an item's step whichever side it is on) */
             w_i[i] += eta_iw * (sw * multiplier * (d_outer * 1.0f) - (d_reg_a * w_i[i]));  /* :279 */
             w_i[j] += eta_j * (sw * multiplier * (d_outer * -1.0f) - (d_reg_a * w_i[j]));   /* :280 */
 
@@ -267,7 +277,7 @@ static int fit_impl(const rfm_oracle_params *p,
             /* (analysis option; always 1 for the reference.  table_every < 0: the tables are frozen -- what the engine's row loop does
              *  when its table trainer is switched off, debug_flags bit 5) */
             const int tab_every = (e == 0 && r < p->table_head_rows) ? p->table_head_every : p->table_every;
-            const int do_tab = tab_every < 0 ? 0 : (tab_every <= 1 || r % tab_every == 0);
+            const int do_tab = tail ? 1 : tab_every < 0 ? 0 : (tab_every <= 1 || r % tab_every == 0);
             const float eta_t = p->table_step > 0.0f ? eta * p->table_step : eta;
             if (p->has_if && do_tab)                                               /* :283-286 */
                 for (int q = 0; q < Q; ++q) {

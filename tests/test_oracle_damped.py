@@ -139,3 +139,18 @@ def test_table_sampling_options_of_the_stand_in(oracle):
     _, sparse = _fit_features(oracle, table_every=7)
     _, head = _fit_features(oracle, table_every=7, table_head_every=1, table_head_rows=300)
     assert not np.array_equal(sparse["v_uf"], ref["v_uf"]) and not np.array_equal(head["v_uf"], sparse["v_uf"])
+
+
+def test_table_tail_of_the_stand_in_moves_the_tables_only(oracle):
+    """`table_tail` (analysis only: table-only visits of random rows behind every epoch -- the sequential stand-in for a table trainer
+    that outlasts the row loops, tools/table_quota_standin.py): none by default; after ONE epoch biases and factor rows are those of
+    the plain call bit for bit and only the dense tables have moved; over two epochs the rows feel the moved tables."""
+    _, ref = _fit_features(oracle, epochs=1)
+    _, none = _fit_features(oracle, epochs=1, table_tail=0)
+    assert all(np.array_equal(ref[k], none[k]) for k in ref)
+    _, tail = _fit_features(oracle, epochs=1, table_tail=400)
+    assert all(np.array_equal(ref[k], tail[k]) for k in ("w_i", "v_u", "v_i"))
+    assert all(not np.array_equal(ref[k], tail[k]) for k in ("v_uf", "v_if", "w_if"))
+    _, ref2 = _fit_features(oracle, epochs=2)
+    _, tail2 = _fit_features(oracle, epochs=2, table_tail=400)
+    assert not np.array_equal(ref2["v_i"], tail2["v_i"])
