@@ -158,6 +158,9 @@ typedef struct {
      * dense feature tables ONLY -- biases and factor rows frozen -- a sequential stand-in for a table trainer that goes on after the row
      * loops of its launch are done (tools/table_quota_standin.py).  0 = none (the reference). */
     int64_t table_tail;
+    /* analysis only: the last `table_quiet_rows` visited rows of every epoch do not train the tables (they still read them) -- a
+     * sequential stand-in for a table trainer that finishes its quota before the row loops are done.  0 = the reference. */
+    int64_t table_quiet_rows;
 } rfm_oracle_params;
 
 /* return codes */
@@ -277,7 +280,7 @@ static int fit_impl(const rfm_oracle_params *p,
             /* (analysis option; always 1 for the reference.  table_every < 0: the tables are frozen -- what the engine's row loop does
              *  when its table trainer is switched off, debug_flags bit 5) */
             const int tab_every = (e == 0 && r < p->table_head_rows) ? p->table_head_every : p->table_every;
-            const int do_tab = tail ? 1 : tab_every < 0 ? 0 : (tab_every <= 1 || r % tab_every == 0);
+            const int do_tab = tail ? 1 : (tab_every < 0 || r >= N - p->table_quiet_rows) ? 0 : (tab_every <= 1 || r % tab_every == 0);
             const float eta_t = p->table_step > 0.0f ? eta * p->table_step : eta;
             if (p->has_if && do_tab)                                               /* :283-286 */
                 for (int q = 0; q < Q; ++q) {

@@ -911,11 +911,12 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // flat out for the length of the launch gets through rows / workgroups of them; measured on config 4's share with the split
         // kernels: 5.8 steps/us against 1450 rows/us of 252 x 48 row groups, i.e. every 250th row in equal time.  The quota is that
         // pace with a wide margin: every (2.4 x row groups / 64)-th row -- 446 on the full chip; the opening launch keeps 1.8 x: every 22nd --
-        // or the caller's `tune_table_every`.  Why 2.4 and not the 1.8 of a trainer that "just finishes first": ranking quality against the
-        // sequential oracle is a HUMP in this number (profiles/r04_notes.md section 11; config-2 shape with tags, three seeds: every
-        // 250th row -3.8 points of hit_rate@10, 290th -0.4, 335th -0.3 ... -0.8 depending on the build, 400th - 450th -0.1, 600th -1.2; at
-        // config 4's shape the 450th ranks 1.6 points better than the 335th) -- a tables kernel that runs for nearly as long as the row
-        // loops beside it (0.9 of their time at the 335th row on config 4's shape) is already on the hump's steep side.  Launches that do
+        // or the caller's `tune_table_every`.  Why 2.4 and not the 1.8 of a trainer that "just finishes first": the rows of an epoch's last
+        // part, which train against tables that have STOPPED moving, are what brings the engine's tables (noisier than the reference's:
+        // 64 staged steps scored on one table state) to the reference's ranking quality, and a tables kernel that runs as long as the row
+        // loops leaves none (profiles/r04_notes.md section 11; config-2 shape with tags, three seeds: every 250th row -3.8 points of
+        // hit_rate@10, 290th -0.4, 335th -0.3 ... -0.8 depending on the build, 400th - 450th -0.1, 600th -1.2; at config 4's shape, where
+        // the 335th row put the tables kernel at 0.94 of the row loops' time, the 450th ranks 1.6 points better).  Launches that do
         // not fill a good part of the chip (fewer than 4096 row groups) keep 1.8: their row loops are latency-bound and slow per row, the
         // trainer is nowhere near their length, and the 3000 x 2000 feature fixture sits within 0.3 point of the REFERENCE there (2.4
         // ranks it a full point ABOVE the reference -- outside the bar from the other side).

@@ -154,3 +154,17 @@ def test_table_tail_of_the_stand_in_moves_the_tables_only(oracle):
     _, ref2 = _fit_features(oracle, epochs=2)
     _, tail2 = _fit_features(oracle, epochs=2, table_tail=400)
     assert not np.array_equal(ref2["v_i"], tail2["v_i"])
+
+
+def test_table_quiet_rows_of_the_stand_in(oracle):
+    """`table_quiet_rows` (analysis only: the last K visited rows of every epoch read the tables and do not train them -- a table trainer
+    that finishes its quota before the row loops; tools/table_quota_standin.py): none by default, a quiet period as long as the epoch is
+    frozen tables, and a shorter one changes what the tables see."""
+    w, ref = _fit_features(oracle)
+    _, none = _fit_features(oracle, table_quiet_rows=0)
+    assert all(np.array_equal(ref[k], none[k]) for k in ref)
+    _, frozen = _fit_features(oracle, table_every=-1)
+    _, quiet_all = _fit_features(oracle, table_quiet_rows=10**9)
+    assert all(np.array_equal(frozen[k], quiet_all[k]) for k in frozen)
+    _, quiet = _fit_features(oracle, table_quiet_rows=300)
+    assert not np.array_equal(quiet["v_uf"], ref["v_uf"]) and not np.array_equal(quiet["v_uf"], w["v_uf"])

@@ -2,7 +2,7 @@
 feature tables are trained when nothing else differs?  The SEQUENTIAL oracle (reference sampler, keyed row shuffle) on planted problems
 with tags that carry signal, the tables updated on every n-th visited row only (`table_every`, oracle/rfm_oracle.c: analysis option) --
 optionally with `--tail K`: K extra table-only steps on random rows after every epoch, the rows frozen (what a tables kernel that
-outlasts the row loops does).  hit_rate@10 on the held-out pairs, evaluated on the CPU.  Analysis tooling (uses oracle/), not product.
+outlasts the row loops does), or `--tail -P`: the last P % of every epoch's rows do not train the tables (a trainer that finishes early).  hit_rate@10 on the held-out pairs, evaluated on the CPU.  Analysis tooling (uses oracle/), not product.
 
     python tools/table_quota_standin.py [--users 30000 --items 12000 --seeds 3 --every 1,30,100,335,1000,3000] [--tail 0,2000]"""
 import argparse
@@ -63,8 +63,10 @@ def job(spec):
     m._init_all(train, uf, itf)
     t0 = time.time()
     kw = dict(table_every=every)
-    if tail:
+    if tail > 0:
         kw["table_tail"] = tail
+    elif tail < 0:                      # (--tail -15 = the last 15 % of every epoch's rows do not train the tables)
+        kw["table_quiet_rows"] = int(len(m.interactions) * (-tail) / 100.0)
     out = orc.fit(m.interactions, m.sample_weight, m.user_items.offsets, m.user_items.items, m.x_uf, m.x_if, m.w_i, m.w_if, m.v_u, m.v_i, m.v_uf, m.v_if,
                   m.alpha, m.beta, m.learning_rate, m.learning_schedule, m.learning_exponent, 1, a["epochs"], perms=None, rng_mode=orc.RNG_COUNTER,
                   seed=100 + seed, membership="binary", **kw)
@@ -84,7 +86,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=10)
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--every", default="1,30,100,335,1000,3000")
-    ap.add_argument("--tail", default="0", help="table-only steps after every epoch (comma list; needs the oracle's table_tail option)")
+    ap.add_argument("--tail", default="0", help="comma list: K > 0 = K table-only visits after every epoch (table_tail); -P = the last P %% of every epoch's rows do not train the tables (table_quiet_rows)")
     ap.add_argument("--processes", type=int, default=min(8, os.cpu_count() or 1))
     a = vars(ap.parse_args())
     specs = [(s, int(e), int(t), a) for t in a["tail"].split(",") for e in a["every"].split(",") for s in range(a["seeds"])]
