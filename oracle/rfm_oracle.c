@@ -161,6 +161,11 @@ typedef struct {
     /* analysis only: the last `table_quiet_rows` visited rows of every epoch do not train the tables (they still read them) -- a
      * sequential stand-in for a table trainer that finishes its quota before the row loops are done.  0 = the reference. */
     int64_t table_quiet_rows;
+    /* analysis only: the visits that train the tables are scored, for the TABLES' update, against a snapshot of the tables taken every
+     * `table_batch` such visits (the rows' own update keeps the current tables) -- a sequential stand-in for the engine's trainer,
+     * which applies batches of 64 staged steps that were all scored on the tables as published when the batch was produced.
+     * 0 / 1 = every visit scored on the current tables (the reference). */
+    int32_t table_batch;
 } rfm_oracle_params;
 
 /* return codes */
@@ -204,19 +209,28 @@ static int fit_impl(const rfm_oracle_params *p,
     const int I = p->I, P = p->P, Q = p->Q, F = p->F;
     rfm_model m = { p->U, I, P, Q, F, p->has_uf, p->has_if, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if };
 
+    /* (analysis option table_batch: the tables as they were when the current batch of table-training visits began) */
+    rfm_model msnap = m;
+    float *snap = NULL;
+    int64_t tab_visits = 0;
+    if (p->table_batch > 1) {
+        snap = (float *)malloc(sizeof(float) * ((size_t)P * F + (size_t)Q * F + (size_t)Q + 1));
+        if (!snap) return RFM_ORACLE_BAD_ARG;
+        msnap.v_uf = snap; msnap.v_if = snap + (size_t)P * F; msnap.w_if = snap + (size_t)P * F + (size_t)Q * F;
+    }
     const float MARGIN = 1.0f;                                  /* :149 */
     const float d_reg_a = 2.0f * p->alpha, d_reg_b = 2.0f * p->beta;   /* :171-172 */
     mt_state mt;
     mt_seed(&mt, p->seed);                                      /* :182 (reference passes 1492) */
     const uint32_t perm_bits = rfm_perm_bits((uint32_t)N), item_bits = rfm_perm_bits((uint32_t)I);
-    if (row_stripe && (p->rng_mode != RFM_RNG_COUNTER || p->stripe_rows < 1 || p->stripe_rows > I)) return RFM_ORACLE_BAD_ARG;
+    if (row_stripe && (p->rng_mode != RFM_RNG_COUNTER || p->stripe_rows < 1 || p->stripe_rows > I)) { free(snap); return RFM_ORACLE_BAD_ARG; }
 
     for (int e = 0; e < p->epochs; ++e) {
         const int epoch = p->epoch_begin + e;
         float eta;
         if (p->schedule == 0) eta = p->learning_rate;                              /* :220-221 */
         else if (p->schedule == 1) eta = (float)(p->learning_rate / pow((double)(epoch + 1), (double)p->learning_exponent)); /* :222-223 */
-        else return RFM_ORACLE_BAD_ARG;                                            /* :224-225 ValueError */
+        else { free(snap); return RFM_ORACLE_BAD_ARG; }                                            /* :224-225 ValueError */
         const uint32_t ekey = rfm_epoch_key(p->seed, (uint32_t)epoch);
         float log_likelihood = 0.0f;                                               /* :228 */
         double log_likelihood64 = 0.0;     /* the same sum without the float accumulator's rounding (ll64_out) */
@@ -282,10 +296,21 @@ static int fit_impl(const rfm_oracle_params *p,
             const int tab_every = (e == 0 && r < p->table_head_rows) ? p->table_head_every : p->table_every;
             const int do_tab = tail ? 1 : (tab_every < 0 || r >= N - p->table_quiet_rows) ? 0 : (tab_every <= 1 || r % tab_every == 0);
             const float eta_t = p->table_step > 0.0f ? eta * p->table_step : eta;
+            float d_outer_t = d_outer;                     /* what the TABLES' update is scored with (analysis option table_batch) */
+            if (snap && do_tab) {
+                if (tab_visits % p->table_batch == 0) {
+                    memcpy(msnap.v_uf, v_uf, sizeof(float) * (size_t)P * F);
+                    memcpy(msnap.v_if, v_if, sizeof(float) * (size_t)Q * F);
+                    memcpy(msnap.w_if, w_if, sizeof(float) * (size_t)Q);
+                }
+                ++tab_visits;
+                const float pu_t = utility(&msnap, u, i) - utility(&msnap, u, j);
+                d_outer_t = (float)(1.0 / (exp((double)pu_t) + 1.0));
+            }
             if (p->has_if && do_tab)                                               /* :283-286 */
                 for (int q = 0; q < Q; ++q) {
                     const float d_w_if = xi[q] - xj[q];
-                    w_if[q] += eta_t * (sw * multiplier * (d_outer * d_w_if) - (d_reg_b * w_if[q]));
+                    w_if[q] += eta_t * (sw * multiplier * (d_outer_t * d_w_if) - (d_reg_b * w_if[q]));
                 }
 
             float *vu = v_u + (size_t)u * F, *vi = v_i + (size_t)i * F, *vj = v_i + (size_t)j * F;
@@ -309,28 +334,28 @@ static int fit_impl(const rfm_oracle_params *p,
                         if (xu[pp] == 0.0f) continue;
                         const float d_v_uf = xu[pp] * (vi[f] - vj[f]);
                         float *t = v_uf + (size_t)pp * F + f;
-                        *t += eta_t * (sw * multiplier * (d_outer * d_v_uf) - (d_reg_b * *t));
+                        *t += eta_t * (sw * multiplier * (d_outer_t * d_v_uf) - (d_reg_b * *t));
                     }
                 if (p->has_if && do_tab)                                           /* :321-326 (post-update v_u) */
                     for (int q = 0; q < Q; ++q) {
                         if (xi[q] - xj[q] == 0.0f) continue;
                         const float d_v_if = (xi[q] - xj[q]) * vu[f];
                         float *t = v_if + (size_t)q * F + f;
-                        *t += eta_t * (sw * multiplier * (d_outer * d_v_if) - (d_reg_b * *t));
+                        *t += eta_t * (sw * multiplier * (d_outer_t * d_v_if) - (d_reg_b * *t));
                     }
             }
         }
         if (ll_out) ll_out[e] = (double)log_likelihood;
         if (ll64_out) ll64_out[e] = log_likelihood64;
         /* :329 assert_finite, same array order as :98-103 */
-        if (!all_finite_sum(w_i, (size_t)I)) return RFM_ORACLE_NONFINITE_BASE + 0;
-        if (!all_finite_sum(w_if, (size_t)Q)) return RFM_ORACLE_NONFINITE_BASE + 1;
-        if (!all_finite_sum(v_u, (size_t)p->U * F)) return RFM_ORACLE_NONFINITE_BASE + 2;
-        if (!all_finite_sum(v_i, (size_t)I * F)) return RFM_ORACLE_NONFINITE_BASE + 3;
-        if (!all_finite_sum(v_uf, (size_t)P * F)) return RFM_ORACLE_NONFINITE_BASE + 4;
-        if (!all_finite_sum(v_if, (size_t)Q * F)) return RFM_ORACLE_NONFINITE_BASE + 5;
+        if (!all_finite_sum(w_i, (size_t)I)) { free(snap); return RFM_ORACLE_NONFINITE_BASE + 0; }
+        if (!all_finite_sum(w_if, (size_t)Q)) { free(snap); return RFM_ORACLE_NONFINITE_BASE + 1; }
+        if (!all_finite_sum(v_u, (size_t)p->U * F)) { free(snap); return RFM_ORACLE_NONFINITE_BASE + 2; }
+        if (!all_finite_sum(v_i, (size_t)I * F)) { free(snap); return RFM_ORACLE_NONFINITE_BASE + 3; }
+        if (!all_finite_sum(v_uf, (size_t)P * F)) { free(snap); return RFM_ORACLE_NONFINITE_BASE + 4; }
+        if (!all_finite_sum(v_if, (size_t)Q * F)) { free(snap); return RFM_ORACLE_NONFINITE_BASE + 5; }
     }
-    return RFM_ORACLE_OK;
+    { free(snap); return RFM_ORACLE_OK; }
 }
 
 int rfm_oracle_fit(const rfm_oracle_params *p,

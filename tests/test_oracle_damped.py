@@ -168,3 +168,16 @@ def test_table_quiet_rows_of_the_stand_in(oracle):
     assert all(np.array_equal(frozen[k], quiet_all[k]) for k in frozen)
     _, quiet = _fit_features(oracle, table_quiet_rows=300)
     assert not np.array_equal(quiet["v_uf"], ref["v_uf"]) and not np.array_equal(quiet["v_uf"], w["v_uf"])
+
+
+def test_table_batch_of_the_stand_in(oracle):
+    """`table_batch` (analysis only: the tables' updates scored on a snapshot of the tables taken every B table-training visits -- the
+    engine's trainer applies batches of staged steps that were scored on one table state; tools/table_quota_standin.py): 0 and 1 are the
+    reference bit for bit, a larger batch changes the tables (and, through them, the rows)."""
+    _, ref = _fit_features(oracle)
+    for b in (0, 1):
+        _, same = _fit_features(oracle, table_batch=b)
+        assert all(np.array_equal(ref[k], same[k]) for k in ref)
+    _, stale = _fit_features(oracle, table_batch=16)
+    assert not np.array_equal(stale["v_uf"], ref["v_uf"]) and not np.array_equal(stale["v_i"], ref["v_i"])
+    assert all(np.isfinite(stale[k]).all() for k in stale)

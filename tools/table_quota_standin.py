@@ -2,9 +2,13 @@
 feature tables are trained when nothing else differs?  The SEQUENTIAL oracle (reference sampler, keyed row shuffle) on planted problems
 with tags that carry signal, the tables updated on every n-th visited row only (`table_every`, oracle/rfm_oracle.c: analysis option) --
 optionally with `--tail K`: K extra table-only steps on random rows after every epoch, the rows frozen (what a tables kernel that
-outlasts the row loops does), or `--tail -P`: the last P % of every epoch's rows do not train the tables (a trainer that finishes early).  hit_rate@10 on the held-out pairs, evaluated on the CPU.  Analysis tooling (uses oracle/), not product.
+outlasts the row loops does), or `--tail -P`: the last P % of every epoch's rows do not train the tables (a trainer that finishes early);
+`--batch B`: the tables' updates are scored on a snapshot of the tables taken every B table-training visits (the engine's trainer
+applies batches of 64 staged steps scored on one table state), `--step s`: the tables' step length scaled by s.  hit_rate@10 on the
+held-out pairs, evaluated on the CPU.  Analysis tooling (uses oracle/), not product.
 
-    python tools/table_quota_standin.py [--users 30000 --items 12000 --seeds 3 --every 1,30,100,335,1000,3000] [--tail 0,2000]"""
+    python tools/table_quota_standin.py [--users 30000 --items 12000 --seeds 3 --every 1,30,100,335,1000,3000] [--tail=0,2000] [--batch 1,64] [--step 1,0.25]
+    (every combination of the four lists is run)"""
 import argparse
 import multiprocessing as mp
 import os
@@ -49,7 +53,7 @@ def hit_rate_cpu(m, test_pairs, k=10, chunk=2048):
 
 
 def job(spec):
-    seed, every, tail, a = spec
+    seed, every, tail, batch, tstep, a = spec
     from oracle import oracle as orc
     from rankfm_amd import EngineOptions, RankFM, synthetic
     orc.build()
@@ -62,7 +66,7 @@ def job(spec):
     np.random.seed(seed)
     m._init_all(train, uf, itf)
     t0 = time.time()
-    kw = dict(table_every=every)
+    kw = dict(table_every=every, table_batch=batch, table_step=(0.0 if tstep == 1.0 else tstep))
     if tail > 0:
         kw["table_tail"] = tail
     elif tail < 0:                      # (--tail -15 = the last 15 % of every epoch's rows do not train the tables)
@@ -72,7 +76,7 @@ def job(spec):
                   seed=100 + seed, membership="binary", **kw)
     m.is_fit = True
     hr = hit_rate_cpu(m, d["test"])
-    return seed, every, tail, hr, float(out["ll64"][-1]) / len(m.interactions), {k: float(np.linalg.norm(getattr(m, k))) for k in WE}, time.time() - t0
+    return seed, (every, tail, batch, tstep), hr, float(out["ll64"][-1]) / len(m.interactions), {k: float(np.linalg.norm(getattr(m, k))) for k in WE}, time.time() - t0
 
 
 def main():
@@ -87,21 +91,24 @@ def main():
     ap.add_argument("--seeds", type=int, default=3)
     ap.add_argument("--every", default="1,30,100,335,1000,3000")
     ap.add_argument("--tail", default="0", help="comma list: K > 0 = K table-only visits after every epoch (table_tail); -P = the last P %% of every epoch's rows do not train the tables (table_quiet_rows)")
+    ap.add_argument("--batch", default="1", help="comma list: table-training visits scored on one snapshot of the tables (1 = the current tables)")
+    ap.add_argument("--step", default="1", help="comma list: scale of the tables' step length")
     ap.add_argument("--processes", type=int, default=min(8, os.cpu_count() or 1))
     a = vars(ap.parse_args())
-    specs = [(s, int(e), int(t), a) for t in a["tail"].split(",") for e in a["every"].split(",") for s in range(a["seeds"])]
+    specs = [(s, int(e), int(t), int(b), float(ts), a) for t in a["tail"].split(",") for e in a["every"].split(",") for b in a["batch"].split(",")
+             for ts in a["step"].split(",") for s in range(a["seeds"])]
     t0 = time.time()
     with mp.get_context("spawn").Pool(a["processes"]) as pool:
         res = pool.map(job, specs, chunksize=1)
     by = {}
-    for seed, every, tail, hr, ll, norms, dt in res:
-        by.setdefault((tail, every), []).append((seed, hr, ll, norms, dt))
+    for seed, key, hr, ll, norms, dt in res:
+        by.setdefault(key, []).append((seed, hr, ll, norms, dt))
     print("%d users x %d items, %d + %d tags, k = %d, lr %.3f, %d epochs, %d seeds (%.0f s)" % (a["users"], a["items"], a["tags"], a["tags"], a["factors"], a["lr"],
                                                                                            a["epochs"], a["seeds"], time.time() - t0))
-    for (tail, every), rows in sorted(by.items()):
+    for (every, tail, batch, tstep), rows in sorted(by.items()):
         rows.sort()
-        print("tables on every %5d-th row, tail %6d: hit_rate@10 %s mean %.4f | LL/N %.4f | |w_i| %.2f |v_uf| %.3f |v_if| %.3f |w_if| %.3f  (%.0f s per run)"
-              % (every, tail, [round(r[1], 4) for r in rows], np.mean([r[1] for r in rows]), np.mean([r[2] for r in rows]), np.mean([r[3]["w_i"] for r in rows]),
+        print("tables on every %5d-th row, tail %6d, batch %3d, step x %.3g: hit_rate@10 %s mean %.4f | LL/N %.4f | |w_i| %.2f |v_uf| %.3f |v_if| %.3f |w_if| %.3f  (%.0f s per run)"
+              % (every, tail, batch, tstep, [round(r[1], 4) for r in rows], np.mean([r[1] for r in rows]), np.mean([r[2] for r in rows]), np.mean([r[3]["w_i"] for r in rows]),
                  np.mean([r[3]["v_uf"] for r in rows]), np.mean([r[3]["v_if"] for r in rows]), np.mean([r[3]["w_if"] for r in rows]), np.mean([r[4] for r in rows])), flush=True)
 
 
