@@ -13,7 +13,7 @@ Engine behaviour that the reference cannot express is carried by `EngineOptions`
 import ctypes as C
 import os
 from collections.abc import Mapping
-from dataclasses import dataclass, field, replace
+from dataclasses import dataclass, field
 from typing import Optional
 
 import numpy as np

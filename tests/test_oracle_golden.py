@@ -84,8 +84,6 @@ def test_counter_mode_negatives_are_valid_and_deterministic(oracle):
     neg, ns = runs[0][1]["neg"], runs[0][1]["nsamp"]
     assert ns.min() >= 1 and ns.max() <= 8
     # every epoch visits every row once (bijective counter permutation); every negative is unobserved for its user
-    from oracle.oracle import C, lib  # noqa: F401
-    import ctypes
     X, off, items = g["interactions"], g["csr_off"], g["csr_items"]
     N = X.shape[0]
     # recompute the visiting order through the spec in include/rfm_rng.h via the oracle's own negatives:

@@ -9,7 +9,6 @@ r03_notes.md.
 (test / analysis infrastructure: uses oracle/)"""
 import os
 import sys
-import time
 
 import numpy as np
 
