@@ -16,8 +16,10 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus:
   roofline     achieved = algorithmic bytes (24F+32 = 1568 B per update) x rows per launch / average
                HIP-event duration of the SGD kernel launch, against the 8 TB/s HBM3E peak; `peak_measured` = what a plain
                streaming kernel gets from this box's HBM (rfm_hbm_probe).  The timed kernel draws its negatives like the
-               reference (uniformly over the whole catalogue); `frac_negative_stripes` = the same fraction with the OPT-IN stripe
-               sampler (EngineOptions.negative_stripes: faster, but measurably worse ranking quality -- not the default)
+               reference (uniformly over the whole catalogue).
+  also         (N = 1, config 2 only) the other BASELINE configurations that fit one GPU, 5 timed epochs each after the config-2 timed
+               region: config 3 (WARP on the same data), config 4 and config 5 as ONE GPU's share of 8 -- the real kernel name,
+               kernel ms min / median, mean draws per update, algorithmic bytes, fraction of the HBM roofline (`--also ""` skips them)
   cpu_baseline the CPU restatement of the reference's `_fit` (oracle/, "port"; MT19937 + linear membership scan like
                the reference) timed on ONE host core (the reference is single-threaded) on a bounded sample
 """
@@ -75,6 +77,67 @@ def cpu_baseline(shard, x_if, w, hyper, has_uf, has_if, seconds_budget=25.0):
                        "oracle/rfm_oracle.c (gcc -O2 -ffast-math, MT19937 + linear membership scan like the reference; 1.19x the time of "
                        "the reference's Cython _fit at k=64 BPR per tools/calibrate_cpu.py), %.1f s on 1 core of %d"
                        % (n_rows, t, os.cpu_count() or 0))
+
+
+def kernel_name(F, max_samples, n_uf, n_if):
+    """the dominant kernel of a chip-filling Hogwild launch, as rocprofv3 --kernel-trace prints it (rfm_sgd_inst.inc picks the
+    instantiation: 16-lane row groups, ceil(F / 16) dwords per lane)"""
+    kpl = (F + 15) // 16
+    if n_uf or n_if:
+        return "rfm::sgd_features_fast_kernel<16, %d, false, 768> (+ rfm::feat_tables_kernel<16, %d, false> beside it on the engine's second stream)" % (kpl, kpl)
+    if max_samples > 1:
+        return "rfm::sgd_warp_kernel<16, %d, false, true, %s>" % (kpl, "true" if F == 16 * kpl else "false")
+    return "rfm::sgd_segments_kernel<16, %d, false, true, false, false>" % kpl
+
+
+def also_workload(name, device, c2_shard, c2_x_if, c2_weights, steps=5, warmup=2):
+    """one more BASELINE configuration on this GPU: `steps` timed epochs of the resident shard, HIP-event kernel time per launch.
+    C3 = config 2's data with WARP (max_samples 50); C4 / C5 = user shard 0 of 8 of the config's ONE data set."""
+    import torch
+    from rankfm_amd import synthetic
+    from rankfm_amd.engine import DeviceSession
+    cfg = synthetic.CONFIGS[name]
+    F = cfg["factors"]
+    n_uf, n_if = cfg.get("n_user_features", 0), cfg.get("n_item_features", 0)
+    t0 = time.perf_counter()
+    if name in ("C4", "C5"):
+        sh = synthetic.make_config_shard(name, rank=0, world=8)
+        data = (sh["interactions"], sh["sample_weight"], sh["csr_offsets"], sh["csr_items"], sh["x_uf"], sh["x_if"])
+        weights = sh["weights"]
+        what = "%s: user shard 0 of 8 of ONE synthetic data set of %d users x %d items x %d interactions (this GPU: %d users, %d interactions, all items)" % (
+            name, cfg["n_users"], cfg["n_items"], cfg["n_interactions"], sh["user_hi"] - sh["user_lo"], len(sh["interactions"]))
+    else:
+        data = (c2_shard["interactions"], c2_shard["sample_weight"], c2_shard["csr_offsets"], c2_shard["csr_items"], c2_shard["x_uf"], c2_x_if)
+        weights = c2_weights
+        what = "%s: config 2's synthetic %d users x %d items x %d interactions" % (name, cfg["n_users"], cfg["n_items"], cfg["n_interactions"])
+    gen_s = time.perf_counter() - t0
+    N = len(data[0])
+    sess = DeviceSession(*data, {k: np.array(v, copy=True) for k, v in weights.items()}, seed=1492, device=device,
+                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
+                         learning_rate=cfg.get("learning_rate", 0.1), max_samples=cfg["max_samples"])
+    sess.run(epochs=warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rep = sess.run(epochs=steps, epoch_begin=warmup)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    launches = rep["launches_per_epoch"]
+    k = np.array(rep["sgd_kernel_ms"], dtype=np.float64) / launches
+    draws = float(np.sum(rep["n_draws"])) / (float(N) * steps)
+    bpu = algorithmic_bytes_per_update(F, n_uf, n_if, draws)
+    assert np.isfinite(float(rep["log_likelihood"][-1])), "%s diverged" % name
+    out = {"workload": "%s, factors=%d, loss=%s%s%s, learning_rate=%g, the reference's sampler" % (
+               what, F, cfg["loss"], " max_samples=%d" % cfg["max_samples"] if cfg["max_samples"] > 1 else "",
+               ", %d + %d dense user / item features" % (n_uf, n_if) if n_uf or n_if else "", cfg.get("learning_rate", 0.1)),
+           "kernel": kernel_name(F, cfg["max_samples"], n_uf, n_if), "rows": N, "steps": steps, "warmup": warmup,
+           "kernel_ms_min": float(k.min()), "kernel_ms_median": float(np.median(k)), "sgd_launches_per_epoch": launches,
+           "mean_draws": draws, "algorithmic_bytes_per_update": bpu,
+           "frac": bpu * (N / launches) / (float(np.median(k)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "updates_per_s": N * steps / elapsed, "sampled_negatives_per_s": float(np.sum(rep["n_draws"])) / elapsed,
+           "data_generation_s": gen_s}
+    del sess
+    torch.cuda.empty_cache()
+    return out
 
 
 def strong_scaling_record(world, rank, device, steps, warmup, barrier):
@@ -139,7 +202,8 @@ def main():
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
     ap.add_argument("--weak", action="store_true", help="configs 4 / 5: weak scaling (every rank its own config-sized shard)")
     ap.add_argument("--learning-rate", type=float, default=0.0, help="override the config's learning rate")
-    ap.add_argument("--negative-stripes", action="store_true", help="time the opt-in stripe sampler instead of the reference's uniform one")
+    ap.add_argument("--negative-stripes", action="store_true", help="time the opt-in stripe sampler (a library built with RFM_STRIPES=1 only) instead of the reference's uniform one")
+    ap.add_argument("--also", default="C3,C4,C5", help="N = 1, config 2: the other configurations appended to the line as `also` (empty = none)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sub-record (config 4 sharded over the ranks)")
     ap.add_argument("--tune", default="", help="geometry overrides of rfm_fit_config (experiments): 'stripe_window=12,segment_rows=32'")
     args = ap.parse_args()
@@ -255,15 +319,13 @@ def main():
         k_ms = float(np.mean(kernel_ms)) / launches                 # average duration of ONE SGD launch
         rows_per_launch = N / launches
         achieved = bytes_per_update * rows_per_launch / (k_ms * 1e-3) / 1e9
-        traffic = atomic_requests = request_ceiling = None
+        traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes / fabric requests per launch, when collected
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = "%s%s" % (args.config, "_stripes" if args.negative_stripes else "")
                 traffic = tj.get(key + "_hbm_bytes_per_launch")
-                atomic_requests = tj.get(key + "_atomic_requests_per_launch")      # TCC_EA0_ATOMIC, all executed memory-side
-                request_ceiling = tj.get("atomic_request_ceiling_per_s")           # tools/microbench/request_rate.hip
             except Exception:
                 traffic = None
         # run-to-run / box-to-box: the same binary differs by 10 - 25 % between boxes of one pool (profiles/r03_notes.md), so the line
@@ -284,8 +346,7 @@ def main():
                        % (geo["stripe_window"], geo["stripe_rows"], geo.get("segment_rows", 32)))
         else:
             sampler = "negatives drawn uniformly over the whole catalogue (the reference's sampler, rankfm/_rankfm.pyx:250-253), user segments <= %d rows" % (geo.get("segment_rows") or 32)
-        peak_measured = frac_other = k_ms_other = None
-        other_name = "whole_catalogue" if args.negative_stripes else "negative_stripes"
+        peak_measured = None
         if world == 1:
             import ctypes as C
             from rankfm_amd import _hip
@@ -293,17 +354,6 @@ def main():
             if _hip.lib().rfm_hbm_probe(C.c_size_t(2 << 30), 5, C.byref(rd), C.byref(cp)) == 0:
                 peak_measured = {"read": rd.value, "copy": cp.value, "unit": "GB/s",
                                  "how": "rfm_hbm_probe: 16 B/lane streaming kernel over 2 GiB, best of 5 launches (copy = read + write bytes)"}
-            if cfg["max_samples"] == 1 and not (n_uf or n_if):
-                # the same workload with the OTHER sampler (the opt-in stripes when the timed run used the reference's uniform draws,
-                # and the other way round): continues from the trained weights
-                from rankfm_amd.engine import DeviceSession
-                other = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"], shard["x_uf"], x_if,
-                                      {k: v.clone() for k, v in sess.weights.items()}, device=device, seed=1492, debug_flags=args.debug_flags,
-                                      negative_stripes=not args.negative_stripes, hogwild_damping=args.damping, check_finite=not args.no_check, **hyper)
-                other.run(epochs=2, epoch_begin=epoch)
-                k_ms_other = float(np.mean(other.run(epochs=5, epoch_begin=epoch + 2)["sgd_kernel_ms"]))
-                frac_other = bytes_per_update * N / (k_ms_other * 1e-3) / 1e9 / HBM_PEAK_GBPS
-                del other
         out = {
             "metric": "(user,item,neg) pairwise updates/sec at k=64; achieved HBM GB/s vs peak",
             "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -328,19 +378,22 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "peak_measured": peak_measured,
-                         "frac_" + other_name: frac_other, "kernel_ms_" + other_name: k_ms_other,
-                         "kernel": "rfm::sgd_features_fast_kernel (+ rfm::feat_tables_kernel beside it)" if (n_uf or n_if) else "rfm::sgd_segments_kernel",
+                         "kernel": kernel_name(F, cfg["max_samples"], n_uf, n_if),
                          "kernel_ms_per_launch": k_ms,
                          "kernel_ms_min": float(k_all.min()), "kernel_ms_median": float(np.median(k_all)), "kernel_ms_max": float(k_all.max()),
                          "frac_best_step": bytes_per_update * rows_per_launch / (float(k_all.min()) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "shader_mhz": mhz,
                          "kernel_ms_median_at_2400mhz": (float(np.median(k_all)) * mhz / 2400.0) if mhz else None,
-                         "atomic_requests_per_update": (atomic_requests / rows_per_launch) if atomic_requests else None,
-                         "frac_of_request_ceiling": (atomic_requests / (k_ms * 1e-3) / request_ceiling) if atomic_requests and request_ceiling else None,
+                         # what bounds the BPR kernel (profiles/r05_notes.md): the memory-side fp32 atomic path retires 20.5 G 64-byte
+                         # requests/s chip-wide on uniform targets, ~16 G/s at config 2's address mix; a BPR update issues 5 (negative) +
+                         # 5 x the share of positives outside the 64 LDS-accumulated rows + the hot rows' publications and sweeps
+                         "atomic_request_capacity_per_s": {"uniform": 20.5e9, "config2_mix": 16.0e9, "source": "tools/microbench/pipe_model.hip, atomic_skew.hip (round 5)"},
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }
         if strong_rec is not None:
             out["strong_scaling"] = strong_rec
+        if world == 1 and args.config == "C2" and not strong and args.also and not args.negative_stripes:
+            out["also"] = [also_workload(name, device, shard, x_if, w) for name in args.also.split(",") if name]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shard, x_if, w, hyper, int(n_uf > 0), int(n_if > 0))
         print(json.dumps(out))

@@ -223,10 +223,15 @@ int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps)
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *dev, void *hip_stream, rfm_fit_report *report);
 
 /* `_fit` on host (numpy) buffers: uploads to `device`, runs rfm_fit_device, downloads the six weight
- * arrays back into the caller's memory.  This is the 1:1 replacement of the reference call site. */
+ * arrays back into the caller's memory.  This is the 1:1 replacement of the reference call site.
+ * Threading: calls on ONE device are serialised inside the library for their whole duration (the reference's `_fit` holds the GIL and
+ * is not re-entrant either, rankfm/_rankfm.pyx:122 + mt19937ar.c:56-57): the staging allocation is one per device.  rfm_fit_device on
+ * caller-owned buffers and streams is re-entrant except for models with features, which share one side stream per device and are
+ * serialised the same way. */
 int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *host, int device, rfm_fit_report *report);
 
-/* rfm_fit_host keeps its device staging allocation between calls (one per device, grown on demand); this releases them all. */
+/* rfm_fit_host keeps its device staging allocation between calls (one per device, grown on demand; an allocation above 1 GiB is
+ * freed when its call returns); this releases them all.  The Python binding calls it at interpreter exit. */
 void rfm_release_cache(void);
 
 /* ---- `_predict` (rankfm/_rankfm.pyx:345-390): pairs are float32 [n,2] indexes, NaN = unknown id ---- */

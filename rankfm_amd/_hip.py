@@ -174,7 +174,17 @@ def lib():
     if L.rfm_abi_version() != ABI_VERSION:
         raise EngineUnavailable("librankfm_hip.so ABI %d != binding ABI %d: rebuild" % (L.rfm_abi_version(), ABI_VERSION))
     _lib = L
+    # rfm_fit_host keeps one staging allocation per device between calls (arenas above 1 GiB are freed when their call returns): give
+    # what is left back before the HIP runtime goes down with the interpreter; release_cache() does it on demand
+    import atexit
+    atexit.register(release_cache)
     return L
+
+
+def release_cache():
+    """free the device staging memory the drop-in `_fit` path keeps between calls (include/rankfm_hip.h rfm_release_cache)"""
+    if _lib is not None:
+        _lib.rfm_release_cache()
 
 
 def status_string(rc):

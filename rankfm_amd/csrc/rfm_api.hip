@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rankfm_hip.h"
@@ -295,8 +296,10 @@ static int g_sm_count = 0;
 FeatSide *feat_side() {
     static FeatSide sides[64];
     static bool made[64];
+    static std::mutex mu;                       // (creation only; the launches that USE the side stream are serialised per device: g_fit_mutex)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     if (!made[dev]) {
         if (hipStreamCreateWithFlags(&sides[dev].stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&sides[dev].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -479,7 +482,17 @@ size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
 // from it instead of reading the device copy back (one 8 (U + 1)-byte transfer and one stream synchronisation less per planned call)
 static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep, const int64_t *host_offsets);
 
+static std::mutex &fit_mutex(int device);
+
 int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep) {
+    // models with features fork their tables kernel onto the engine's ONE side stream per device: such calls take the device's lock
+    // (rfm_fit_host holds it for every call); everything else runs on the caller's stream and buffers only
+    if (cfg && (cfg->has_user_features || cfg->has_item_features)) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(fit_mutex(dev));
+        return fit_device_impl(cfg, b, hip_stream, rep, nullptr);
+    }
     return fit_device_impl(cfg, b, hip_stream, rep, nullptr);
 }
 
@@ -604,10 +617,19 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     // launched (one 4-byte read-back per call that checked; the reference spins forever at rankfm/_rankfm.pyx:250-253).
     // (only when a list CAN hold every item: some degree >= I -- known exactly when the offsets are on the host for the plan, else
     // bounded by N >= I; every other call skips the synchronisation)
+    // (the lists may hold MORE than this call's interactions -- fit_partial keeps earlier items -- so N bounds a degree only when the
+    //  offsets are not at hand; with the offsets on the host every degree is looked at, whatever N)
+    const int64_t *deg_off = !off.empty() ? off.data() : host_offsets;
     bool may_saturate = N >= (int64_t)cfg->n_items;
-    if (may_saturate && !off.empty()) {
+    if (deg_off) {
         may_saturate = false;
-        for (int u = 0; u < cfg->n_users && !may_saturate; ++u) may_saturate = off[(size_t)u + 1] - off[u] >= (int64_t)cfg->n_items;
+        for (int u = 0; u < cfg->n_users && !may_saturate; ++u) may_saturate = deg_off[(size_t)u + 1] - deg_off[u] >= (int64_t)cfg->n_items;
+    } else if (!may_saturate && cfg->plan_token <= 0 && !use_segments && N > 0) {
+        // device-resident lists of unknown length (rows kernel): the lists' total length bounds every degree -- one 8-byte read-back
+        int64_t nnz_dev = 0;
+        RFM_HIP(hipMemcpyAsync(&nnz_dev, b->csr_offsets + cfg->n_users, sizeof nnz_dev, hipMemcpyDeviceToHost, stream));
+        RFM_HIP(hipStreamSynchronize(stream));
+        may_saturate = nnz_dev >= (int64_t)cfg->n_items;
     }
     if (cfg->plan_token <= 0 && may_saturate) {
         unsigned int flags = 0;
@@ -1105,12 +1127,24 @@ static HostArena &host_arena(int device) {
     static HostArena arenas[64];
     return arenas[device >= 0 && device < 64 ? device : 0];
 }
+// rfm_fit_host is serialised PER DEVICE for the whole call: the staging arena is one allocation per device that a larger call
+// re-allocates, and models with features fork their tables kernel onto one side stream per device.  ctypes releases the GIL around
+// the call, so two Python threads can arrive here together; the second simply waits.  (rfm_fit_device on caller-owned
+// buffers and streams takes the same lock only when the model has features, for the side stream.)
+static std::mutex &fit_mutex(int device) {
+    static std::mutex mus[64];
+    return mus[device >= 0 && device < 64 ? device : 0];
+}
+// A staging arena above this size is not kept between calls (a multi-GB buffer of one large fit would otherwise stay resident for
+// the life of the process and starve later torch / predict allocations).
+constexpr size_t kArenaKeepBytes = (size_t)1 << 30;
 
 void rfm_release_cache(void) {
     int n = 0, cur = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return;
     (void)hipGetDevice(&cur);
     for (int d = 0; d < n && d < 64; ++d) {
+        std::lock_guard<std::mutex> lock(fit_mutex(d));
         HostArena &c = host_arena(d);
         if (c.ptr) { (void)hipSetDevice(d); (void)hipFree(c.ptr); c.ptr = nullptr; c.bytes = 0; }
     }
@@ -1128,6 +1162,7 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         g_last_error = "no HIP device visible";
         return RFM_ERR_NO_DEVICE;
     }
+    std::lock_guard<std::mutex> fit_lock(fit_mutex(device));
     RFM_HIP(hipSetDevice(device));
     const int64_t N = cfg->n_interactions;
     const size_t U = cfg->n_users, I = cfg->n_items, P = cfg->n_user_features, Q = cfg->n_item_features, F = cfg->n_factors;
@@ -1154,8 +1189,9 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
     };
     // ONE device allocation for everything (14 hipMalloc / hipFree pairs cost more than a millisecond of a 2.6 ms epoch), carved
     // on 256-byte boundaries -- and KEPT between calls (per device, grown when a call needs more, released by rfm_release_cache or
-    // at process exit): the reference's call site calls `_fit` once per fit, but epoch-by-epoch callers (fit_partial loops) pay the
-    // allocation and the implicit synchronisation of hipFree every time otherwise.  Not re-entrant, like the reference's `_fit`.
+    // at process exit; arenas above 1 GiB are freed when the call returns): the reference's call site calls `_fit` once per fit, but
+    // epoch-by-epoch callers (fit_partial loops) pay the allocation and the implicit synchronisation of hipFree every time otherwise.
+    // Calls on one device are serialised (fit_mutex), like the reference's `_fit` under the GIL.
     size_t total = 0;
     for (Item &it : items) total += align_up(it.bytes ? it.bytes : 16);
     HostArena &cache = host_arena(device);
@@ -1167,7 +1203,9 @@ int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *h, int device
         cache.bytes = total;
     }
     char *arena = cache.ptr;
-    auto cleanup = [&]() {};
+    auto cleanup = [&]() {
+        if (cache.bytes > kArenaKeepBytes) { (void)hipFree(cache.ptr); cache.ptr = nullptr; cache.bytes = 0; }
+    };
     // (Pinning the caller's weight arrays for the call -- hipHostRegister, so that both of their copies run as direct DMA -- was
     //  measured in round 4: 8.8 ms against 8.7 - 9.4 ms for a one-epoch config-2 call: registering 39 MB costs what it saves.)
     size_t at = 0;

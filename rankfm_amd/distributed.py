@@ -109,6 +109,18 @@ class SharedTables:
         scale[a:a + self._sizes["w_i"]] = torch.clamp(float(bias_damping) / n, min=1.0 / world_size, max=1.0)
         scale[self._tail_at:] = 1.0
         self.merge_scale = scale if world_size > 1 else None
+        self._clamp = (np.asarray(item_counts_all_ranks, dtype=np.float64), int(world_size), damping, bias_damping, float(learning_rate))
+        self._clamp_window = 1.0
+
+    def set_clamp_window(self, window):
+        """the clamp rule's item counts are per EPOCH; an exchange that closes the share `window` of an epoch sees window x counts"""
+        c = getattr(self, "_clamp", None)
+        if c is None or self.merge_scale is None or abs(float(window) - self._clamp_window) < 1e-12:
+            return
+        counts, world, damping, bias_damping, lr = c
+        self.set_merge_damping(counts * float(window), world, damping, bias_damping, lr)
+        self._clamp = c
+        self._clamp_window = float(window)
 
     # The curvature rule (the default from round 3's end on).  An item row that a rank steps n times in an exchange window moves
     # about (1 - rho^n) of the way to where that rank's data would take it, rho = 1 - kappa, kappa = eta x (curvature of the loss
@@ -125,10 +137,10 @@ class SharedTables:
     # point of each other), c_w = 0.3 for the biases (0.25 holds everywhere, 0.12 lets them run away at learning rate 0.1).
     CURVATURE_FACTORS, CURVATURE_BIASES = 0.1, 0.3
 
-    def set_merge_curvature(self, local_item_counts, world_size, learning_rate=0.1, c_factors=None, c_biases=None, group=None, mean_vu2=None):
+    def set_merge_curvature(self, local_item_counts, world_size, learning_rate=0.1, c_factors=None, c_biases=None, group=None, mean_vu2=None, n_users=1):
         """arm the curvature rule: `local_item_counts` [I] = this rank's updates of every item per exchange window.  The scale
         itself is computed at every exchange (it needs the ranks' current mean |v_u|^2): by exchange_fused inside the one all-reduce
-        (`mean_vu2` = this rank's mean |v_u|^2 now; rank 0's is what everybody starts from), or by refresh_merge_scale + two small
+        (`mean_vu2` / `n_users` = this rank's mean |v_u|^2 and user count now; the mean over all ranks' users is what everybody starts from), or by refresh_merge_scale + two small
         collectives (the round-3 form, kept for callers that drive the exchange themselves)."""
         self._n_local = torch.as_tensor(np.asarray(local_item_counts, dtype=np.float64), dtype=torch.float64, device=self.flat.device)
         self._curvature = (float(learning_rate), float(self.CURVATURE_FACTORS if c_factors is None else c_factors),
@@ -141,10 +153,12 @@ class SharedTables:
         self._n_total = self._n_local.clone()
         if dist.is_available() and dist.is_initialized() and world_size > 1:
             dist.all_reduce(self._n_total, op=dist.ReduceOp.SUM, group=group)
-        m0 = torch.tensor([float(mean_vu2) if mean_vu2 is not None else 0.0], dtype=torch.float64, device=self.flat.device)
+        # (the mean over ALL ranks' users -- a sum / count all-reduce: rank 0 may own no users, and a zero here would turn the first
+        #  exchange into an unscaled sum of the ranks' deltas; `mean_vu2` = this rank's mean, `n_users` its user count)
+        m0 = torch.tensor([(float(mean_vu2) if mean_vu2 is not None else 0.0) * float(n_users), float(n_users)], dtype=torch.float64, device=self.flat.device)
         if dist.is_available() and dist.is_initialized() and world_size > 1:
-            dist.broadcast(m0, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
-        self._mean_vu2 = m0[0]
+            dist.all_reduce(m0, op=dist.ReduceOp.SUM, group=group)
+        self._mean_vu2 = m0[0] / torch.clamp(m0[1], min=1.0)
 
     def refresh_merge_scale(self, sum_vu2, n_users, group=None, eta=None, window=1.0):
         """the curvature rule's scale for the coming exchange: `sum_vu2` / `n_users` = this rank's sum of |v_u|^2 and user count
@@ -357,6 +371,8 @@ class ShardedTrainer:
             s, n = self.user_norms_fn() if self.user_norms_fn is not None else (0.0, 0)
             eta = self.eta_fn(epoch) if (self.eta_fn is not None and epoch is not None) else None
             self.shared.refresh_merge_scale(float(s), n, self.group, eta=eta, window=window)
+        elif not self.average and hasattr(self.shared, "set_clamp_window"):
+            self.shared.set_clamp_window(window)
         self.shared.all_reduce_deltas(self.group, self.average)
 
     def check_peers(self, synchronize=False):
@@ -426,12 +442,13 @@ def agree_on_merge_damping(shared, shard, group=None, merge_damping=None, syncs_
         v_u = np.asarray(shard.get("v_u", np.zeros((0, 1), np.float32)))
         mean_vu2 = float((v_u.astype(np.float64) ** 2).sum() / max(len(v_u), 1))
         # (counts per EPOCH: the share of an epoch an exchange closes is passed at the exchange, ShardedTrainer._exchange)
-        shared.set_merge_curvature(counts.cpu().numpy(), dist.get_world_size(group), learning_rate=learning_rate, group=group, mean_vu2=mean_vu2)
+        shared.set_merge_curvature(counts.cpu().numpy(), dist.get_world_size(group), learning_rate=learning_rate, group=group, mean_vu2=mean_vu2,
+                                   n_users=len(v_u))
         return
     dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-    # the damping counts updates per exchange window
-    shared.set_merge_damping(counts.cpu().numpy() / (1 if syncs_per_epoch == "auto" else max(int(syncs_per_epoch), 1)), dist.get_world_size(group), merge_damping,
-                             learning_rate=learning_rate)
+    # (counts per EPOCH: the share of an epoch an exchange closes is applied at the exchange, SharedTables.set_clamp_window -- with the
+    #  "auto" cadence it changes during the fit)
+    shared.set_merge_damping(counts.cpu().numpy(), dist.get_world_size(group), merge_damping, learning_rate=learning_rate)
 
 
 def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=None,
@@ -643,6 +660,9 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     for e in range(epochs):
         out = trainer.run_epoch(e)
         if verbose:
+            # a peer whose slice failed raised right behind the exchange and will not join the collective below: look at the failure
+            # flag of that exchange FIRST (the healthy ranks used to wait in the all-reduce for the NCCL watchdog)
+            trainer.check_peers(synchronize=True)
             ll = torch.tensor([float(np.sum(out.get("log_likelihood", out.get("ll", [0.0]))))], dtype=torch.float64,
                               device=trainer.shared.flat.device)
             if world > 1:

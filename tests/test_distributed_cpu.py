@@ -131,7 +131,7 @@ def _fused_worker(rank, world, port, out_dir):
     rng = np.random.default_rng(10 + rank)
     shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
     counts = rng.integers(0, 400, I).astype(np.float64) * (rng.random(I) < 0.7)
-    shared.set_merge_curvature(counts, world, learning_rate=0.1, mean_vu2=0.5 + rank)            # (rank 0's 0.5 is what everybody uses)
+    shared.set_merge_curvature(counts, world, learning_rate=0.1, mean_vu2=0.5 + rank, n_users=10 + rank)     # (everybody starts from the mean over ALL ranks' users)
     out = {}
     for x, vu2 in enumerate((3.0 + rank, 7.0 + 2 * rank)):                                       # two exchanges: the second uses the first's mean
         shared.begin_epoch()
@@ -146,7 +146,8 @@ def _fused_worker(rank, world, port, out_dir):
 def test_fused_exchange_is_the_curvature_rule_in_one_all_reduce(tmp_path):
     """SharedTables.exchange_fused (round 4: deltas, curvature terms, |v_u|^2 sums and failure flags in ONE all-reduce of the bucket,
     no host round trip) against the rule computed by hand from curvature_log_rho / curvature_terms / curvature_scales: the first
-    exchange uses rank 0's mean |v_u|^2 from arming time, the second the mean the ranks summed during the first."""
+    exchange uses the mean |v_u|^2 over all ranks' users from arming time (a sum / count all-reduce: rank 0 may own no users), the second
+    the mean the ranks summed during the first."""
     from rankfm_amd.distributed import curvature_log_rho, curvature_scales, curvature_terms
     world = 2
     mp.spawn(_fused_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
@@ -154,7 +155,7 @@ def test_fused_exchange_is_the_curvature_rule_in_one_all_reduce(tmp_path):
     ref = SharedTables({k: _problem()[3][k] for k in SHARED_NAMES}, torch.device("cpu"))
     T = ref._tail_at
     cur = r[0]["start"][:T].astype(np.float64)
-    mean = 0.5
+    mean = (0.5 * 10 + 1.5 * 11) / 21.0
     for x, vu2 in enumerate(((3.0, 4.0), (7.0, 9.0))):
         assert np.array_equal(r[0]["flat%d" % x], r[1]["flat%d" % x])                             # replicas agree bit for bit
         log_rho = curvature_log_rho(0.1, SharedTables.CURVATURE_FACTORS, SharedTables.CURVATURE_BIASES, mean)

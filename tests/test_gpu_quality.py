@@ -74,16 +74,16 @@ def test_feature_model_matches_the_reference():
         assert 0.5 < got[k] / want[k] < 2.0, (cols[k], got[k], want[k])
 
 
-def test_default_sampler_holds_the_quality_bar_at_a_chip_filling_size_and_the_stripes_cost_what_is_documented():
+def test_default_sampler_holds_the_quality_bar_at_a_chip_filling_size():
     """Ranking quality at a size whose launches fill a good part of the chip -- 30,000 users x 12,000 items, 3.7 M interactions,
     BPR, k = 32 (full factor rows: the opt-in stripe sampler plans stripes here), 5 epochs, FIVE seeds -- against the sequential
     oracle drawing its negatives like the reference (uniformly over the catalogue, rankfm/_rankfm.pyx:250-253), from the same
     initial weights.
       default engine (uniform sampler)   hit_rate@10 within 1.0 point (measured -0.17: profiles/r03_notes.md), |v_u|, |v_i| 2 %,
                                          |w_i| 4 %;
-      opt-in stripe sampler              NOT held to the bar -- that is why it is opt-in: measured -1.03 points here (and -2.3 at
-                                         100 k x 50 k); asserted to stay within the 2 points its documentation states and to
-                                         really have planned stripes.
+      opt-in stripe sampler              only when the library was built with it (RFM_STRIPES=1; not in the default build since round 5):
+                                         NOT held to the bar -- measured -1.03 points here (and -2.3 at 100 k x 50 k); asserted to stay
+                                         within the 2 points its documentation states and to really have planned stripes.
     The five seeds' data and oracle fits are CPU work and run in a process pool; the engine runs in this process."""
     import multiprocessing as mp
     from oracle.planted_worker import fit_planted
@@ -91,8 +91,10 @@ def test_default_sampler_holds_the_quality_bar_at_a_chip_filling_size_and_the_st
     U, I, F, E, SEEDS = 30_000, 12_000, 32, 5, 5
     with mp.get_context("spawn").Pool(SEEDS) as pool:
         jobs = pool.map(fit_planted, [(s, U, I, F, E) for s in range(SEEDS)])
-    hits = {"oracle": [], "default": [], "stripes": []}
-    norms = {"oracle": [], "default": [], "stripes": []}
+    from conftest import stripes_built
+    sides = ["oracle", "default"] + (["stripes"] if stripes_built() else [])
+    hits = {k: [] for k in sides}
+    norms = {k: [] for k in sides}
     for job in jobs:
         seed = job["seed"]
         train, test = pd.DataFrame(job["train"], columns=["u", "i"]), pd.DataFrame(job["test"], columns=["u", "i"])
@@ -113,13 +115,14 @@ def test_default_sampler_holds_the_quality_bar_at_a_chip_filling_size_and_the_st
             norms[side].append([np.linalg.norm(m.v_u), np.linalg.norm(m.v_i), np.linalg.norm(m.w_i)])
     mean = {k: float(np.mean(v)) for k, v in hits.items()}
     print("hit_rate@10 over %d seeds:" % SEEDS, {k: np.round(v, 4).tolist() for k, v in hits.items()}, "means", mean,
-          "norms / oracle - 1:", {k: np.round(np.mean(norms[k], axis=0) / np.mean(norms["oracle"], axis=0) - 1.0, 4).tolist() for k in ("default", "stripes")})
+          "norms / oracle - 1:", {k: np.round(np.mean(norms[k], axis=0) / np.mean(norms["oracle"], axis=0) - 1.0, 4).tolist() for k in sides[1:]})
     assert mean["oracle"] > 0.7                                              # the task is learnable
     assert abs(mean["default"] - mean["oracle"]) <= 0.010, mean
     got, want = np.mean(norms["default"], axis=0), np.mean(norms["oracle"], axis=0)
     np.testing.assert_allclose(got[:2], want[:2], rtol=0.02)
     np.testing.assert_allclose(got[2], want[2], rtol=0.04)
-    assert abs(mean["stripes"] - mean["oracle"]) <= 0.020, mean
+    if "stripes" in mean:
+        assert abs(mean["stripes"] - mean["oracle"]) <= 0.020, mean
 
 
 # ---- the quality bar AT BASELINE config 2's shape: 100,000 users x 50,000 items, ~4.5 M training rows --------------

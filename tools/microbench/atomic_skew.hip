@@ -17,7 +17,8 @@ __device__ __forceinline__ uint32_t zipf_rank(uint32_t h, float lo, float span, 
 }
 
 // frac_zipf_x256: share of the row updates that go to Zipf rows (the rest uniform), in 1/256
-template <bool LOADS>
+// SPLIT: segment k of a row lives in table k (a row's four segments are 64-byte lines far apart instead of 256 contiguous bytes)
+template <bool LOADS, bool SPLIT>
 __global__ void __launch_bounds__(1024) skew_kernel(float *table, float *bias, uint32_t n_items, uint32_t skip, int frac_zipf_x256, int iters, float *out) {
     const uint32_t lane = threadIdx.x & 63, sub = lane & 15;
     const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -30,11 +31,11 @@ __global__ void __launch_bounds__(1024) skew_kernel(float *table, float *bias, u
         row = (uint32_t)(((uint64_t)row * 2654435761ull) % n_items);          // ranks scattered over the table
         if (LOADS) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc += table[(size_t)row * 64 + sub + 16 * k];
+            for (int k = 0; k < 4; ++k) acc += SPLIT ? table[((size_t)k * n_items + row) * 16 + sub] : table[(size_t)row * 64 + sub + 16 * k];
             if (sub == 0) acc += bias[(size_t)row * 16];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(table + (size_t)row * 64 + sub + 16 * k, 1e-9f);
+        for (int k = 0; k < 4; ++k) unsafeAtomicAdd(SPLIT ? table + ((size_t)k * n_items + row) * 16 + sub : table + (size_t)row * 64 + sub + 16 * k, 1e-9f);
         if (sub == 0) unsafeAtomicAdd(bias + (size_t)row * 16, 1e-9f);
     }
     if (acc == 123.456f) out[0] = acc;
@@ -48,7 +49,8 @@ int main() {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int cus = 256, iters = 320;                 // 256 x 64 groups x 320 = 5.2 M row updates = 26 M requests
     const double rows = (double)cus * 64 * iters;
-    const uint32_t skips[] = {0, 16, 64, 256, 1024, 4096};
+    const uint32_t skips[] = {0, 64, 256, 1024};
+    for (int split = 0; split < 2; ++split)
     for (int loads = 0; loads < 2; ++loads)
         for (int frac : {0, 128, 256})
             for (uint32_t skip : skips) {
@@ -56,13 +58,15 @@ int main() {
                 float ms = 0;
                 for (int rep = 0; rep < 2; ++rep) {
                     (void)hipEventRecord(e0);
-                    if (loads) skew_kernel<true><<<cus, 1024>>>(table, bias, n_items, skip, frac, iters, out);
-                    else skew_kernel<false><<<cus, 1024>>>(table, bias, n_items, skip, frac, iters, out);
+                    if (loads && split) skew_kernel<true, true><<<cus, 1024>>>(table, bias, n_items, skip, frac, iters, out);
+                    else if (loads) skew_kernel<true, false><<<cus, 1024>>>(table, bias, n_items, skip, frac, iters, out);
+                    else if (split) skew_kernel<false, true><<<cus, 1024>>>(table, bias, n_items, skip, frac, iters, out);
+                    else skew_kernel<false, false><<<cus, 1024>>>(table, bias, n_items, skip, frac, iters, out);
                     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
                     (void)hipEventElapsedTime(&ms, e0, e1);
                 }
-                printf("%s zipf share %3d/256, head of %4u ranks left out: %7.3f ms  %6.2f G row updates/s  %6.2f G requests/s\n",
-                       loads ? "load+atomic" : "atomic only", frac, skip, ms, rows / ms * 1e-6, rows * 5 / ms * 1e-6);
+                printf("%s %s zipf share %3d/256, head of %4u ranks left out: %7.3f ms  %6.2f G row updates/s  %6.2f G requests/s\n",
+                       split ? "split " : "contig", loads ? "load+atomic" : "atomic only", frac, skip, ms, rows / ms * 1e-6, rows * 5 / ms * 1e-6);
             }
     return 0;
 }
