@@ -87,7 +87,8 @@ def kernel_name(F, max_samples, n_uf, n_if):
         return "rfm::sgd_features_fast_kernel<16, %d, false, 768> (+ rfm::feat_tables_kernel<16, %d, false> beside it on the engine's second stream)" % (kpl, kpl)
     if max_samples > 1:
         return "rfm::sgd_warp_kernel<16, %d, false, true, %s>" % (kpl, "true" if F == 16 * kpl else "false")
-    return "rfm::sgd_segments_kernel<16, %d, false, true, false, false>" % kpl
+    # (BPR with hot-row accumulators; full factor rows run on segment-major item rows: the last template argument)
+    return "rfm::sgd_segments_kernel<16, %d, false, true, false, false, %s>" % (kpl, "true" if F == 16 * kpl else "false")
 
 
 def also_workload(name, device, c2_shard, c2_x_if, c2_weights, steps=5, warmup=2):

@@ -117,7 +117,7 @@ typedef struct rfm_fit_config {
                                       bit 6: models with features: no table-friendly opening launch in the fit's first epoch (experiments),
                                       bit 7: row groups stride the epoch's segment order statically instead of taking tickets (experiments),
                                       bit 8: the item damping scales an item's step only when it is the POSITIVE item, the round-3 rule (experiments),
-                                      bit 9: (unused) */
+                                      bit 9: chip-filling BPR launches keep the item factor rows row-major (no segment-major working copy; experiments) */
     int32_t epoch_part_index;      /* with epoch_parts > 1: run only part k (0-based) of each epoch's visiting order -- lets a */
     int32_t epoch_parts;           /* multi-GPU caller exchange item deltas several times per epoch; 0 or 1 = whole epochs    */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
@@ -131,7 +131,7 @@ typedef struct rfm_fit_config {
     int32_t tune_stripe_window;    /* rows per group between stripe changes (auto: 8 I / groups, at most 32) */
     int32_t tune_stripe_rows;      /* items per stripe (auto: groups x window / 2, at most what LDS holds); -1 = none: the pipelined
                                       row loop of the stripe kernel with whole-catalogue draws */
-    int32_t tune_hot_publications; /* publications of a hot row per epoch and workgroup (auto: 48) */
+    int32_t tune_hot_publications; /* publications of a hot row per epoch and workgroup (auto: 32 for BPR without features, else 48) */
     int32_t tune_feature_waves;    /* wavefronts per workgroup of the features kernel, 2..16 (auto: 16) */
     int32_t tune_table_producers;      /* features kernel: step-producer workgroups feeding the table trainer, 1..16 (auto: 3 on a
                                       full chip, 2 / 1 on small launches) */

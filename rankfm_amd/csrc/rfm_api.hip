@@ -142,6 +142,20 @@ __global__ void bias_pad_kernel(float *__restrict__ w_i, float *__restrict__ w_p
     } else w_i[i] = w_pad[(size_t)i * kBiasStride];
 }
 
+// item factor rows row-major <-> segment-major (SgdArgs::vi_split): dword f of item i at ((f / 16) * I + i) * 16 + f % 16.  One thread
+// per 16-byte quarter of a 64-byte segment; both sides are 16-byte aligned (F is a multiple of 16).
+template <bool TO_SPLIT>
+__global__ void __launch_bounds__(256) vi_split_kernel(float4 *__restrict__ row_major, float4 *__restrict__ seg_major, int n_items, int n_segs) {
+    const size_t total = (size_t)n_items * n_segs * 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) {
+        // q walks the segment-major copy: (seg, item, quarter)
+        const size_t seg = q / ((size_t)n_items * 4), rest = q % ((size_t)n_items * 4);
+        const size_t item = rest >> 2, quarter = rest & 3;
+        const size_t r = (item * n_segs + seg) * 4 + quarter;
+        if (TO_SPLIT) seg_major[q] = row_major[r]; else row_major[r] = seg_major[q];
+    }
+}
+
 __global__ void item_count_kernel(const int32_t *__restrict__ interactions, long long n, int *__restrict__ count) {
     for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x)
         atomicAdd(count + interactions[2 * r + 1], 1);
@@ -193,6 +207,7 @@ struct Workspace {
     float *multiplier;            // [max_samples + 1]
     float *w_pad;                     // [n_items * kBiasStride] item biases, one 64-byte line each (SgdArgs::w_stride)
     float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: zero between launches
+    float *vi_split;                  // [I, F] segment-major working copy of the item factor rows (SgdArgs::vi_split), or nullptr
     unsigned int *feat_flags;     // [kFeatFlagWords] producer / trainer hand-shake of the features kernel (zero between launches)
     unsigned long long *feat_clock;   // [4] wall-clock ticks of the last launch's tables kernel (begin, end) and row-loop kernel (begin, end)
     unsigned long long *sclk;         // [4] SgdArgs::sclk of the last launch
@@ -204,6 +219,12 @@ struct Workspace {
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 constexpr int kMaxHot = 64;                      // hot-row accumulator slots per workgroup (LDS: kMaxHot * (F + 2) floats)
+// Publications of a hot row per epoch and workgroup (tune_hot_publications).  A publication is not only five atomic requests into the
+// bins: with 48 of them every seventh row of config 2 publishes, i.e. nearly every second wavefront row step runs the publication
+// block for one of its four rows.  Measured at full size against the sequential oracle (tools/pub_margin.py, profiles/r05_notes.md;
+// epoch 1 / 2 log-likelihood, |w_i|, kernel): 48: +0.40 % / -0.04 %, +0.25 %, 2.67 ms; 32: +0.55 % / -0.05 %, +0.36 %, 2.58 ms;
+// 24: +0.73 % / -0.07 %, +0.50 %, 2.52 ms; 16: +1.08 % / -0.10 %, +0.75 %, 2.49 ms.  32 keeps half the parity bound (1 %) as margin.
+constexpr double kHotPublications = 32.0;
 
 constexpr int kStripeSegmentRows = 16;         // segments of a plan that uses negative stripes (see rfm_fit_device, "segment length")
 // (a user of degree d is cut into ceil(d / rows) <= d / rows + 1 segments)
@@ -229,7 +250,7 @@ static int64_t ticket_windows(const rfm_fit_config *c) {
 }
 
 static Workspace carve(void *base, int epochs, int max_samples, int n_items, int n_users, int64_t n_rows, size_t n_ring, int n_factors,
-                       int seg_rows_min, int64_t windows_per_epoch) {
+                       int seg_rows_min, int64_t windows_per_epoch, bool vi_split) {
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
@@ -256,8 +277,19 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.hot_bins_w = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot);
     w.windows_per_epoch = windows_per_epoch;
     w.tickets = (unsigned int *)(p + o);         o += align_up(sizeof(unsigned int) * kTicketWords * (size_t)windows_per_epoch * (size_t)epochs);
+    // (never read before written, never zeroed: last)
+    w.vi_split = vi_split ? (float *)(p + o) : nullptr;
+    if (vi_split) o += align_up(sizeof(float) * (size_t)n_items * (size_t)n_factors);
     w.bytes = o;
     return w;
+}
+
+// calls that MAY run on segment-major item rows (SgdArgs::vi_split; the workspace then holds the copy): BPR without features, Hogwild,
+// full factor rows of 16-lane row groups (k = 16, 32, 48, 64, 96, 128); debug_flags bit 9 keeps the rows row-major (experiments)
+static bool vi_split_eligible(const rfm_fit_config *c) {
+    const ShapeEntry *sh = pick_shape(c->n_factors);
+    return sh && sh->group == 16 && c->n_factors == sh->group * sh->kpl && c->max_samples == 1 && !c->has_user_features && !c->has_item_features &&
+           c->mode == RFM_MODE_HOGWILD && c->sampler == RFM_SAMPLER_UNIFORM && !(c->debug_flags & 512);
 }
 
 static size_t feat_table_floats(const rfm_fit_config *c) {
@@ -475,7 +507,7 @@ int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps)
 
 size_t rfm_fit_workspace_bytes(const rfm_fit_config *cfg) {
     if (validate(cfg) != RFM_OK) return 0;
-    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg), ticket_windows(cfg)).bytes;
+    return carve(nullptr, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg), ticket_windows(cfg), vi_split_eligible(cfg)).bytes;
 }
 
 // `host_offsets`: the caller's HOST copy of the CSR offsets, when it has one (rfm_fit_host): the planner then cuts the user segments
@@ -506,7 +538,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     if ((rc = device_ok()) != RFM_OK) return rc;
     const int E = cfg->epochs;
     const int64_t N = cfg->n_interactions;
-    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg), ticket_windows(cfg));
+    const Workspace ws = carve(b->workspace, E, cfg->max_samples, cfg->n_items, cfg->n_users, N, feat_ring_floats(cfg), cfg->n_factors, min_segment_rows(cfg), ticket_windows(cfg), vi_split_eligible(cfg));
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
@@ -526,7 +558,9 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     std::vector<float> mult((size_t)cfg->max_samples + 1, 0.0f);
     for (int s = 1; s <= cfg->max_samples; ++s)
         mult[s] = (float)(log((double)((cfg->n_items - 1) / s)) / log((double)cfg->n_items));
-    RFM_HIP(hipMemsetAsync((char *)b->workspace + ws.volatile_offset, 0, ws.bytes - ws.volatile_offset, stream));
+    // (the segment-major copy of the item rows at the workspace's end is written before it is read: not zeroed)
+    const size_t zero_end = ws.vi_split ? (size_t)((const char *)ws.vi_split - (const char *)b->workspace) : ws.bytes;
+    RFM_HIP(hipMemsetAsync((char *)b->workspace + ws.volatile_offset, 0, zero_end - ws.volatile_offset, stream));
     RFM_HIP(hipMemcpyAsync(ws.multiplier, mult.data(), mult.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     std::vector<uint32_t> mt(625);
     if (cfg->rng == RFM_RNG_MT19937) {
@@ -840,10 +874,11 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             scale[i] = n > damp_m ? (float)(damp_m / n) : 1.0f;
         }
         std::vector<int32_t> h_item(kMaxHot, 0), h_period(kMaxHot, 1);
-        const double hot_pubs = cfg->tune_hot_publications > 0 ? (double)cfg->tune_hot_publications : 48.0;
+        // (BPR without features: 32, measured; WARP and the features kernels keep the 48 their parity figures were measured with)
+        const double hot_pubs = cfg->tune_hot_publications > 0 ? (double)cfg->tune_hot_publications : (cfg->max_samples == 1 && !feat ? kHotPublications : 48.0);
         for (int s = 0; s < (use_hot ? n_hot : 0); ++s) {
             const int i = hot_order[s];
-            // publish about 48 times per epoch and workgroup: ~2 % of the row's updates are pending chip-wide at any time
+            // publish about kHotPublications times per epoch and workgroup: ~3 % of the row's updates are pending chip-wide at any time
             int period = (int)((double)item_count[i] / ((double)grid * hot_pubs) + 0.5);
             if (period < 1) period = 1;
             if (period > 64) period = 64;
@@ -866,6 +901,13 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     // (with stripes the candidates' biases are LDS reads, so WARP pads as well)
     const bool pad_bias = !serial && (use_stripes || cfg->max_samples <= 4);
     if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, damp ? ws.pos_scale : nullptr, cfg->n_items);
+    // Chip-filling BPR launches with hot-row accumulators (the launches that sit at the memory-side atomic path's capacity) work on a
+    // segment-major copy of the item factor rows for the length of the call (SgdArgs::vi_split); the caller's v_i is written back
+    // behind the last epoch.  The epoch tail reads the copy: its sums and its finiteness check do not depend on the order of the elements.
+    const bool vi_split = ws.vi_split && use_hot && !feat && !use_stripes && !single_group && vi_split_eligible(cfg);
+    const int vi_segs = cfg->n_factors / 16;
+    const int vi_grid = (int)std::min<size_t>(4096, ((size_t)cfg->n_items * vi_segs * 4 + 255) / 256);
+    if (vi_split) vi_split_kernel<true><<<dim3(vi_grid), dim3(256), 0, stream>>>((float4 *)b->v_i, (float4 *)ws.vi_split, cfg->n_items, vi_segs);
     // timing events: destroyed on every exit path
     struct Events {
         std::vector<hipEvent_t> ev;
@@ -898,7 +940,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         SgdArgs a;
         a.interactions = b->interactions; a.sample_weight = b->sample_weight;
         a.csr_off = b->csr_offsets; a.csr_items = b->csr_items; a.x_uf = b->x_uf; a.x_if = b->x_if;
-        a.w_i = pad_bias ? ws.w_pad : b->w_i; a.w_stride = pad_bias ? kBiasStride : 1; a.scale_in_pad = pad_bias ? 1 : 0; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
+        a.w_i = pad_bias ? ws.w_pad : b->w_i; a.w_stride = pad_bias ? kBiasStride : 1; a.scale_in_pad = pad_bias ? 1 : 0; a.w_if = b->w_if; a.v_u = b->v_u; a.v_i = vi_split ? ws.vi_split : b->v_i; a.v_uf = b->v_uf; a.v_if = b->v_if;
         a.perm = b->perms ? b->perms + (size_t)e * N : nullptr;
         a.multiplier = ws.multiplier; a.mt_state = ws.mt_state;
         a.ll = ws.ll + e; a.draws = ws.draws + e; a.error_flags = ws.error_flags;
@@ -924,7 +966,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         a.feat_ring = ws.feat_ring; a.feat_flags = ws.feat_flags; a.n_producers = n_producers; a.feat_frozen = feat_frozen ? 1 : 0;
         a.tickets = nullptr;
         a.damp_positive_only = (cfg->debug_flags & 256) ? 1 : 0;
-        a.reserved_i32 = 0;
+        a.vi_split = vi_split ? 1 : 0;
         a.feat_clock = ws.feat_clock;
         a.sclk = ws.sclk;
         a.table_quota = 0;
@@ -1022,7 +1064,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
 
         if (cfg->check_finite || cfg->want_penalty) {
             TailArgs t;
-            const float *ptrs[6] = {b->w_i, b->w_if, b->v_u, b->v_i, b->v_uf, b->v_if};
+            const float *ptrs[6] = {b->w_i, b->w_if, b->v_u, vi_split ? ws.vi_split : b->v_i, b->v_uf, b->v_if};
             const unsigned long long lens[6] = {
                 (unsigned long long)cfg->n_items, (unsigned long long)cfg->n_item_features,
                 (unsigned long long)cfg->n_users * cfg->n_factors, (unsigned long long)cfg->n_items * cfg->n_factors,
@@ -1039,6 +1081,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             else tail_kernel<false><<<dim3(tgrid), dim3(256), 0, stream>>>(t);
         }
     }
+    if (vi_split) vi_split_kernel<false><<<dim3(vi_grid), dim3(256), 0, stream>>>((float4 *)b->v_i, (float4 *)ws.vi_split, cfg->n_items, vi_segs);
     RFM_HIP(hipGetLastError());
 
     // ---- one synchronisation: bring the per-epoch results back

@@ -18,9 +18,11 @@ namespace rfm {
 //   TMODE    with LDSF: what the step updates (sgd_features_kernel).  0 = the rows only (v_u, v_i, w_i; the tables are a read-only
 //            copy), 1 = the tables only (the table trainer: plain read-modify-write on the master copy, groups of a wavefront one
 //            after the other), 2 = both (one group alone: the reference's sequential step)
+//   VISPLIT  the item factor rows are segment-major (SgdArgs::vi_split): full rows of 16-lane groups, no features, no stripes
 template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false, bool WARPB = true,
-          bool STRIPE = false, int TMODE = 0>
+          bool STRIPE = false, int TMODE = 0, bool VISPLIT = false>
 struct RowStep {
+    static_assert(!VISPLIT || (G == 16 && !FEAT && !STRIPE && !SERIAL), "segment-major item rows: the plain Hogwild row loops of 16-lane groups");
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
     const int F;
@@ -132,7 +134,10 @@ struct RowStep {
                 return;
             }
         }
-        load_row<FRESH>(a.v_i + (size_t)it * F, v);
+        if constexpr (VISPLIT) {
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) v[k] = load_f32<FRESH>(a.v_i + vi_off(it, k));
+        } else load_row<FRESH>(a.v_i + (size_t)it * F, v);
         w = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
     }
     // raw draw -> candidate item (and its stripe row)
@@ -151,6 +156,11 @@ struct RowStep {
     // (stripe launches are planned for full factor rows only: the factor count is the compile-time constant G * KPL there)
 
     __device__ __forceinline__ int dword_f(int k) const { return sub + G * k; }
+    // element index in `v_i` of this lane's dword k of item `it`
+    __device__ __forceinline__ size_t vi_off(int32_t it, int k) const {
+        if constexpr (VISPLIT) return ((size_t)k * (size_t)a.n_items + (size_t)it) * G + sub;
+        else return (size_t)it * F + dword_f(k);
+    }
     // (stripe launches are planned for FULL factor rows only, F == G * KPL: no per-dword predicate -- a v_cmp, an exec-mask
     //  save and a branch around every load, atomic and LDS update of the row loop otherwise)
     __device__ __forceinline__ bool dword_ok(int k) const { return STRIPE || dword_f(k) < F; }
@@ -592,9 +602,9 @@ struct RowStep {
                 const int f = dword_f(k);
                 if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u);
                 if (HOT && slot >= 0) hot_add(hot_acc + slot * F + f, d_i);
-                else apply_f32<SERIAL>(a.v_i + (size_t)i * F + f, vi[k], d_i);
+                else apply_f32<SERIAL>(a.v_i + vi_off(i, k), vi[k], d_i);
                 if (STRIPE && jrow >= 0) { hot_add(sn_delta + jrow * (F + 1) + f, d_j); hot_add(sn_sum + f, d_j); }
-                else apply_f32<SERIAL>(a.v_i + (size_t)j * F + f, vj[k], d_j);
+                else apply_f32<SERIAL>(a.v_i + vi_off(j, k), vj[k], d_j);
             }
         }
         if constexpr (VU_REGS && UPD_ROWS) {
@@ -613,12 +623,12 @@ struct RowStep {
                         if (!dword_ok(k)) continue;
                         const float d = hot_take(hot_acc + slot * F + dword_f(k));
                         if (d != 0.0f)
-                            atomic_add_f32(c.hot_direct ? a.v_i + (size_t)i * F + dword_f(k)
-                                                        : c.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * c.n_hot + slot) * F + dword_f(k), d);
+                            atomic_add_f32(c.hot_direct ? a.v_i + vi_off(i, k)
+                                                        : c.hot_bins_v + hot_bin_v(c, blockIdx.x % kHotBins, slot, dword_f(k)), d);
                     }
                     if (sub == 0) {
                         const float d = hot_take(hot_accw + slot);
-                        if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * c.n_hot + slot, d);
+                        if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + hot_bin_w(c, blockIdx.x % kHotBins, slot), d);
                     }
                 }
             }

@@ -64,8 +64,8 @@ struct SgdArgs {
     // one atomic add of the total into v_i / w_i), and hot_reduce_kernel drains what is left when the launch ends.
     // With few workgroups (fewer than a quarter of the lines) there is little contention and a sweeping turn would take
     // long: hot_direct = 1 publishes straight into the rows.
-    float *hot_bins_v;                          // [kHotBins, n_hot, F]
-    float *hot_bins_w;                          // [kHotBins, n_hot]
+    float *hot_bins_v;                          // [kHotBins, n_hot, F]   (hot_bin_v)
+    float *hot_bins_w;                          // [kHotBins, n_hot]      (hot_bin_w)
     int32_t hot_direct;
     const unsigned int *sw_max_bits;            // bits of max |sample_weight| (plan): range of the fixed-point hot sums
     // negative stripes (segments kernel, STRIPE instantiation; include/rfm_rng.h "negative stripes"): the workgroup draws the
@@ -83,13 +83,29 @@ struct SgdArgs {
     // a ticket counter instead of striding the order with the number of groups (SegmentTickets below); nullptr = static stride
     unsigned int *tickets;                      // the launch's counter of order positions handed out, zero at launch
     int32_t damp_positive_only;                 // experiments: the round-3 rule (an item's scale applies to its step as the POSITIVE item only)
-    int32_t reserved_i32;
+    // Item factor rows SEGMENT-MAJOR (round 5): dword f of item i at ((f / 16) * I + i) * 16 + f % 16 of `v_i` -- the four 64-byte
+    // segments of a row are lines 64 I bytes apart instead of 256 contiguous bytes.  The memory-side atomic path is slower on skewed
+    // targets (a warm row's in-flight updates queue at its memory channel: profiles/r05_notes.md), and a contiguous row puts all
+    // four of its segments on one channel; spread out, config 2's address mix retires 18.1 - 18.6 G requests/s instead of 16.6 -
+    // 16.8 (tools/microbench/atomic_skew.hip).  The engine works on such a copy in its workspace for the length of a call (the
+    // caller's v_i keeps the reference's layout before and after); full factor rows of 16-lane groups only.
+    int32_t vi_split;
     // features: the table trainer applies EXACTLY table_quota staged steps per launch (rounded up to whole batches) -- a number the host
     // derives from the launch's rows and geometry, not from when the row loops happen to finish (feat_tables_kernel)
     int64_t table_quota;
     unsigned long long *feat_clock;             // [4] wall-clock ticks: tables kernel begin | end | row-loop kernel begin | end (diagnostics)
     unsigned long long *sclk;                   // [4] workgroup 0 of the row-loop kernel: wall clock (100 MHz) at its start | end, shader cycle counter at its start | end
 };
+// Hot-row bins: element index of dword f of slot `slot` in bin `bin` (hot_bin_v) / of the slot's bias (hot_bin_w).
+// (Round 5 measured a staggered layout -- segment-major, an odd number of lines between bins, so that the sixteen bins of a slot and the
+// four segments of a bin row do not sit at power-of-two strides -- against this dense one: 2.647 / 2.694 against 2.727 / 2.662 ms on
+// config 2, nothing; profiles/r05_notes.md.)
+__device__ __forceinline__ size_t hot_bin_v(const SgdArgs &a, int bin, int slot, int f) { return ((size_t)bin * a.n_hot + slot) * a.n_factors + f; }
+__device__ __forceinline__ size_t hot_bin_w(const SgdArgs &a, int bin, int slot) { return (size_t)bin * a.n_hot + slot; }
+// element index of dword f of item `item` in SgdArgs::v_i (see vi_split)
+__device__ __forceinline__ size_t vi_index(const SgdArgs &a, int32_t item, int f) {
+    return a.vi_split ? ((size_t)(f >> 4) * (size_t)a.n_items + (size_t)item) * 16 + (size_t)(f & 15) : (size_t)item * a.n_factors + f;
+}
 constexpr int kTicketWords = 16;                // one counter per launch, on a 64-byte line of its own
 constexpr int kHotBins = 16;
 
@@ -375,27 +391,27 @@ __device__ __forceinline__ void hot_sweep_line(const SgdArgs &a, int line) {
     const int lane = threadIdx.x & 63, d16 = lane & 15, quad = lane >> 4;
     const int F = a.n_factors, lpr = (F + 15) / 16;
     const bool bias = line >= a.n_hot * lpr;
-    float *src, *dst;
-    size_t bin_stride;
+    float *dst;
     bool ok;
+    int slot, f = 0;
     if (!bias) {
-        const int slot = line / lpr, f = (line % lpr) * 16 + d16;
+        slot = line / lpr;
+        f = (line % lpr) * 16 + d16;
         ok = f < F;
-        src = a.hot_bins_v + (size_t)slot * F + f;
-        bin_stride = (size_t)a.n_hot * F;
-        dst = a.v_i + (size_t)a.hot_item[slot] * F + f;
+        dst = a.v_i + vi_index(a, a.hot_item[slot], ok ? f : 0);
     } else {
-        const int slot = (line - a.n_hot * lpr) * 16 + d16;
+        slot = (line - a.n_hot * lpr) * 16 + d16;
         ok = slot < a.n_hot;
-        src = a.hot_bins_w + slot;
-        bin_stride = (size_t)a.n_hot;
-        dst = a.w_i + (size_t)a.hot_item[ok ? slot : 0] * a.w_stride;
+        if (!ok) slot = 0;
+        dst = a.w_i + (size_t)a.hot_item[slot] * a.w_stride;
     }
     float acc = 0.0f;
     if (ok) {
 #pragma unroll
-        for (int b = 0; b < kHotBins; b += 4)
-            acc += __hip_atomic_exchange(src + (size_t)(b + quad) * bin_stride, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int b = 0; b < kHotBins; b += 4) {
+            float *src = bias ? a.hot_bins_w + hot_bin_w(a, b + quad, slot) : a.hot_bins_v + hot_bin_v(a, b + quad, slot, f);
+            acc += __hip_atomic_exchange(src, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     acc += __shfl_xor(acc, 16);
     acc += __shfl_xor(acc, 32);

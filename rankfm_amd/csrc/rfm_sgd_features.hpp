@@ -758,11 +758,11 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
                         const float d = (float)__hip_atomic_exchange(hot_acc + slot * F + sub + G * k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * hot_unit;
                         if (d != 0.0f)
                             atomic_add_f32(c.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
-                                                        : c.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * n_hot + slot) * F + sub + G * k, d);
+                                                        : c.hot_bins_v + hot_bin_v(c, blockIdx.x % kHotBins, slot, sub + G * k), d);
                     }
                     if (sub == 0) {
                         const float d = (float)__hip_atomic_exchange(hot_accw + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * hot_unit;
-                        if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * n_hot + slot, d);
+                        if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + hot_bin_w(c, blockIdx.x % kHotBins, slot), d);
                     }
                 }
                 if (a.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next row reads what this one wrote
@@ -795,11 +795,11 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
             for (int k = threadIdx.x; k < n_hot * F; k += blockDim.x) {
                 const float d = (float)hot_acc[k] * hot_unit;
                 if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.v_i + (size_t)a.hot_item[k / F] * F + (k % F)
-                                                           : a.hot_bins_v + (size_t)(blockIdx.x % kHotBins) * n_hot * F + k, d);
+                                                           : a.hot_bins_v + hot_bin_v(a, blockIdx.x % kHotBins, k / F, k % F), d);
             }
             for (int k = threadIdx.x; k < n_hot; k += blockDim.x) {
                 const float d = (float)hot_accw[k] * hot_unit;
-                if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * n_hot + k, d);
+                if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + hot_bin_w(a, blockIdx.x % kHotBins, k), d);
             }
         }
         flush_counters(a, ll_acc, draw_acc);

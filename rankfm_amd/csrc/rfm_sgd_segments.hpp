@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) sgd_rows_kernel(const SgdArgs a) {
 // the window ends every stripe row is published with ONE set of atomics however many updates it received -- with
 // 64 groups x 32 rows on 256 stripe rows about eight.  That takes the negative item's 4 + 1 memory-side atomic requests per
 // update (of ~10, the kernel's bound: DESIGN.md section 7) down to ~0.6, and the negative's row reads from 5 to ~0.6.
-template <int G, int KPL, bool FRESH, bool HOT = false, bool WARPB = true, bool STRIPE = false>
+template <int G, int KPL, bool FRESH, bool HOT = false, bool WARPB = true, bool STRIPE = false, bool VISPLIT = false>
 __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_kernel(const SgdArgs a) {
     constexpr bool FEAT = false;        // (models with features run sgd_features_kernel)
     const int lane = threadIdx.x & 63;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
     const int F = STRIPE ? G * KPL : a.n_factors;
     extern __shared__ __attribute__((aligned(16))) float lds_tables[];
     lds_float *lds = (lds_float *)lds_tables;
-    typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, WARPB, STRIPE> Step;
+    typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, WARPB, STRIPE, 0, VISPLIT> Step;
     Step step(a, sub, a.v_uf, a.v_if, a.w_if);
     if constexpr (HOT) {
         // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] touch counters
@@ -322,12 +322,12 @@ __global__ void __launch_bounds__((HOT || STRIPE) ? 1024 : 256) sgd_segments_ker
         __syncthreads();
         for (int k = threadIdx.x; k < a.n_hot * F; k += blockDim.x) {
             const float d = (float)step.hot_acc[k] * step.kHotUnit;
-            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.v_i + (size_t)a.hot_item[k / F] * F + (k % F)
-                                                       : a.hot_bins_v + (size_t)(blockIdx.x % kHotBins) * a.n_hot * F + k, d);
+            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.v_i + vi_index(a, a.hot_item[k / F], k % F)
+                                                       : a.hot_bins_v + hot_bin_v(a, blockIdx.x % kHotBins, k / F, k % F), d);
         }
         for (int k = threadIdx.x; k < a.n_hot; k += blockDim.x) {
             const float d = (float)step.hot_accw[k] * step.kHotUnit;
-            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + k, d);
+            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + hot_bin_w(a, blockIdx.x % kHotBins, k), d);
         }
     }
     flush_counters(a, ll_acc, draw_acc);

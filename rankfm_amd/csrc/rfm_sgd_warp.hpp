@@ -287,11 +287,11 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                             const float d = step.hot_take(step.hot_acc + slot * F + sub + G * k);
                             if (d != 0.0f)
                                 atomic_add_f32(c.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
-                                                            : c.hot_bins_v + ((size_t)(blockIdx.x % kHotBins) * c.n_hot + slot) * F + sub + G * k, d);
+                                                            : c.hot_bins_v + hot_bin_v(c, blockIdx.x % kHotBins, slot, sub + G * k), d);
                         }
                         if (sub == 0) {
                             const float d = step.hot_take(step.hot_accw + slot);
-                            if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * c.n_hot + slot, d);
+                            if (d != 0.0f) atomic_add_f32(c.hot_direct ? a.w_i + (size_t)i * a.w_stride : c.hot_bins_w + hot_bin_w(c, blockIdx.x % kHotBins, slot), d);
                         }
                     }
                 }
@@ -332,11 +332,11 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
         for (int k = threadIdx.x; k < a.n_hot * F; k += blockDim.x) {
             const float d = (float)step.hot_acc[k] * step.kHotUnit;
             if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.v_i + (size_t)a.hot_item[k / F] * F + (k % F)
-                                                       : a.hot_bins_v + (size_t)(blockIdx.x % kHotBins) * a.n_hot * F + k, d);
+                                                       : a.hot_bins_v + hot_bin_v(a, blockIdx.x % kHotBins, k / F, k % F), d);
         }
         for (int k = threadIdx.x; k < a.n_hot; k += blockDim.x) {
             const float d = (float)step.hot_accw[k] * step.kHotUnit;
-            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + (size_t)(blockIdx.x % kHotBins) * a.n_hot + k, d);
+            if (d != 0.0f) atomic_add_f32(a.hot_direct ? a.w_i + (size_t)a.hot_item[k] * a.w_stride : a.hot_bins_w + hot_bin_w(a, blockIdx.x % kHotBins, k), d);
         }
     }
     flush_counters(a, ll_acc, draw_acc);

@@ -30,11 +30,13 @@ def pick(kernels, prefix):
 
 
 def test_the_bench_kernel_and_the_warp_kernels_do_not_spill(kernels):
-    # config 2 / config 1: BPR with hot-row accumulators, 16-lane row groups, k = 64 / 32 / 16
+    # config 2 / config 1: BPR with hot-row accumulators, 16-lane row groups, k = 64 / 32 / 16 -- on segment-major item rows (the bench
+    # kernel since round 5) and on row-major ones
     for kpl in (1, 2, 4):
         for fresh in ("false", "true"):
-            for r in pick(kernels, "sgd_segments_kernel<16, %d, %s, true, false, false>" % (kpl, fresh)):
-                assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 128, r
+            for split in ("true", "false"):
+                for r in pick(kernels, "sgd_segments_kernel<16, %d, %s, true, false, false, %s>" % (kpl, fresh, split)):
+                    assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 128, r
     # configs 3 / 5 and every other factor count: the WARP state machine
     for r in pick(kernels, "sgd_warp_kernel<16, "):
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, r
