@@ -156,7 +156,7 @@ def strong_scaling_record(world, rank, device, steps, warmup, barrier):
                  x_uf=sh["x_uf"], v_u=w["v_u"])
     hyper = dict(alpha=0.01, beta=0.1, learning_rate=cfg["learning_rate"], learning_schedule="constant", learning_exponent=0.25, max_samples=1)
     trainer, _ = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, sh["x_if"], hyper, device, seed=1492,
-                                     has_user_features=1, has_item_features=1)
+                                     has_user_features=1, has_item_features=1, overlap=True)
     broadcast_from_rank0([trainer.shared.flat])
     epoch = 0
     for _ in range(warmup):
@@ -167,6 +167,7 @@ def strong_scaling_record(world, rank, device, steps, warmup, barrier):
     for _ in range(steps):
         rep = trainer.run_epoch(epoch)
         epoch += 1
+    trainer.finish()
     barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,6 +199,7 @@ def main():
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--syncs-per-epoch", default="auto", help="item-delta exchanges per epoch (N > 1): a number, or 'auto' = the production default "
                     "(8 per epoch during a fit's first 8 epochs, 1 afterwards: rankfm_amd.distributed.ShardedTrainer)")
+    ap.add_argument("--blocking-exchange", action="store_true", help="N > 1: every exchange blocks (rounds 2-4) instead of the one-window-late merge")
     ap.add_argument("--factors", type=int, default=0, help="override the config's factor count (experiments)")
     ap.add_argument("--shape", type=int, default=0, help="experiment: 1-based index into the kernel shape table")
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
@@ -276,7 +278,7 @@ def main():
                                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
                                         shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check,
                                         tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv},
-                                        negative_stripes=args.negative_stripes)
+                                        negative_stripes=args.negative_stripes, overlap=world > 1 and not args.blocking_exchange)
     broadcast_from_rank0([trainer.shared.flat])
 
     def barrier():
@@ -289,6 +291,8 @@ def main():
         trainer.run_epoch(epoch)
         epoch += 1
     kernel_ms, shader_mhz, draws = [], [], 0
+    if world > 1 and hasattr(trainer.shared, "exposed_exchange_ms"):
+        trainer.shared.exposed_exchange_ms()          # (forget the warm-up's waits)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -298,8 +302,26 @@ def main():
             shader_mhz.append(float(sess.geometry().get("shader_mhz", 0.0)))
         draws += int(rep["n_draws"][0])
         epoch += 1
+    trainer.finish()                  # (late merge: the final blocking exchange belongs to the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
+    # N > 1: what an exchange costs by itself (one blocking all-reduce of a bucket-sized buffer, HIP events) and how much of the
+    # exchanges the rank's stream actually waited for (SharedTables.exposed_exchange_ms: ~0 when the late merge hides them)
+    exchange_ms = exposed_ms = None
+    n_exchanges = 0
+    if world > 1:
+        scratch = torch.zeros_like(trainer.shared.flat)
+        dist.all_reduce(scratch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        dist.all_reduce(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        exchange_ms = float(e0.elapsed_time(e1))
+        del scratch
+        if hasattr(trainer.shared, "exposed_exchange_ms"):
+            exposed_ms, n_exchanges = trainer.shared.exposed_exchange_ms()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -371,6 +393,11 @@ def main():
                        "merge_rule": ("curvature rule in ONE all-reduce of the bucket per exchange (SharedTables.exchange_fused); exchanges per epoch: %s%s"
                                       % (args.syncs_per_epoch, " = 8 during a fit's first 8 epochs, 1 afterwards (the timed steps are epochs %d .. %d)"
                                          % (args.warmup, args.warmup + args.steps - 1) if args.syncs_per_epoch == "auto" else "")) if world > 1 else None,
+                       # (N > 1) one all-reduce of the bucket by itself, and the stream time per epoch spent WAITING for exchanges
+                       "exchange": ({"payload_bytes": trainer.shared.payload_bytes, "exchange_ms": exchange_ms,
+                                     "late_merge": not args.blocking_exchange,
+                                     "exposed_exchange_ms_per_epoch": (exposed_ms / args.steps) if exposed_ms is not None else None,
+                                     "waits_timed": n_exchanges} if world > 1 else None),
                        "sgd_launches_per_epoch": launches, "waves_per_launch": rep["waves_per_launch"],
                        "mean_draws_per_update": mean_draws,
                        # WARP lines also carry the rate of sampled negatives (accepted draws, whole job)

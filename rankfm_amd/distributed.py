@@ -248,6 +248,114 @@ class SharedTables:
         self._mean_vu2 = torch.where(users > 0, t[2 * n_items].to(torch.float64) / torch.clamp(users, min=1.0), self._mean_vu2)
         return t[2 * n_items + 2]
 
+    # ---- the exchange OFF the critical path (round 5): one-window-late merge ------------------------------------------------------
+    # The blocking rule makes every rank wait for the all-reduce of window k before it trains window k + 1: at BASELINE config 4 an
+    # exchange moves 52 MB while a rank's share of an epoch is ~4 ms of SGD, and the default cadence is 8 exchanges per epoch for a
+    # fit's first 8 epochs -- as long in RCCL as in SGD.  Late merge: a rank trains window k + 1 on ITS OWN result of window k while the
+    # all-reduce of the window-k deltas runs beside it (torch's async collective: RCCL's own stream), and replaces its own window-k
+    # delta by the merged one when window k + 1 is done:
+    #     after window k (tables T = B_k + d_k, B_k = the snapshot the window started from):
+    #         own_new = T - B_k                                   (this rank's delta of window k, tail = its curvature terms)
+    #         if a reduction is pending (window k - 1):  wait;  T += scale_{k-1} * SUM_{k-1} - own_{k-1}          (the correction)
+    #         own = own_new;  SUM = all_reduce(copy of own), asynchronously
+    #     finish_late():  wait;  T += scale * SUM - own.
+    # Summed over the windows every rank ends at  B_0 + sum_k scale_k * SUM_k : the replicas are identical again after finish_late(),
+    # and equal to the blocking rule with every merged delta applied one window late.  Between exchanges a rank's tables differ from its
+    # peers' by its own un-merged window -- by design.  rho of window k's scale comes from the mean |v_u|^2 agreed at the last COMPLETED
+    # reduction (two windows back instead of one).
+    def exchange_late(self, group, sum_vu2, n_users, failed=False, eta=None, window=1.0):
+        """submit this window's deltas, apply the previous window's correction; returns the (device) sum of the failure flags that
+        came back with the PREVIOUS window's reduction (0 when none was pending)"""
+        lr, c_v, c_w = self._curvature
+        if eta is not None:
+            lr = float(eta)
+        n_items = self._shapes["w_i"][0]
+        T = self._tail_at
+        if getattr(self, "_late_own", None) is None:
+            self._late_own, self._late_sum = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+            self._late_work, self._late_meta = None, None
+            self.late_wait_events = []                     # (CUDA) event pairs around every wait for a reduction: the EXPOSED exchange time
+        t = self.tail
+        log_rho_v = torch.log1p(-torch.clamp(lr * c_v * self._mean_vu2, max=0.5))
+        log_rho_w = float(np.log1p(-min(lr * c_w, 0.5)))
+        t[:n_items] = (-torch.expm1(log_rho_v * (self._n_local * window))).to(torch.float32)
+        t[n_items:2 * n_items] = (-torch.expm1(log_rho_w * (self._n_local * window))).to(torch.float32)
+        t[2 * n_items] = sum_vu2
+        t[2 * n_items + 1] = float(n_users)
+        t[2 * n_items + 2] = 1.0 if failed else 0.0
+        if failed:
+            self.flat[:T].copy_(self.start[:T])            # a failed slice contributes no deltas (they may be non-finite)
+        if getattr(self, "_late_tmp", None) is None:
+            self._late_tmp = torch.zeros_like(self.flat)
+        torch.sub(self.flat, self.start, out=self._late_tmp)                 # this window's own delta (tail: its curvature terms)
+        flag = self._late_apply()                                            # the PREVIOUS window's correction (waits for its reduction)
+        self.tail.zero_()                                                    # (the tail belongs to the exchange, not to the tables)
+        # a peer failed in the previous window and has left: no further collective is launched (the caller raises).  Reading the flag
+        # is a 4-byte device read-back; the reduction it belongs to was launched a whole window ago.
+        if float(flag) > 0:
+            return flag
+        self._late_own, self._late_tmp = self._late_tmp, self._late_own
+        self._late_sum.copy_(self._late_own)
+        self._late_meta = (log_rho_v, log_rho_w, float(window))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            self._late_work = dist.all_reduce(self._late_sum, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        else:
+            self._late_work = True                         # (one rank: the "reduction" is the copy)
+        return flag
+
+    def _late_apply(self):
+        """wait for the pending reduction and replace this rank's own delta of that window by the merged one"""
+        zero = torch.zeros((), dtype=torch.float32, device=self.flat.device)
+        if getattr(self, "_late_work", None) is None:
+            return zero
+        if self._late_work is not True:
+            if self.flat.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._late_work.wait()
+                e1.record()
+                self.late_wait_events.append((e0, e1))
+            else:
+                self._late_work.wait()
+        self._late_work = None
+        log_rho_v, log_rho_w, window = self._late_meta
+        world = self._world
+        n_items, T, F = self._shapes["w_i"][0], self._tail_at, self._shapes["v_i"][1]
+        ts = self._late_sum[T:]
+        t_v, t_w = ts[:n_items].to(torch.float64), ts[n_items:2 * n_items].to(torch.float64)
+        lo = 1.0 / world
+        sv = torch.where(t_v > 0, -torch.expm1(log_rho_v * (self._n_total * window)) / torch.clamp(t_v, min=1e-30), torch.ones_like(t_v)).clamp(lo, 1.0)
+        sb = torch.where(t_w > 0, -torch.expm1(log_rho_w * (self._n_total * window)) / torch.clamp(t_w, min=1e-30), torch.ones_like(t_w)).clamp(lo, 1.0)
+        a = self._starts["v_i"]
+        self.merge_scale[a:a + self._sizes["v_i"]].view(n_items, F).copy_(sv.to(torch.float32)[:, None].expand(n_items, F))
+        a = self._starts["w_i"]
+        self.merge_scale[a:a + self._sizes["w_i"]] = sb.to(torch.float32)
+        # T += scale * SUM - own   (one fused pass on the tables part of the bucket)
+        self.flat[:T].addcmul_(self.merge_scale[:T], self._late_sum[:T]).sub_(self._late_own[:T])
+        users = ts[2 * n_items + 1].to(torch.float64)
+        self._mean_vu2 = torch.where(users > 0, ts[2 * n_items].to(torch.float64) / torch.clamp(users, min=1.0), self._mean_vu2)
+        return ts[2 * n_items + 2].clone()
+
+    def finish_late(self, group=None):
+        """the final, blocking exchange of the late merge: afterwards every rank holds the same tables.  Each rank has summed the same
+        merged deltas onto the same start, but in its own order (its own deltas first, the corrections later): the replicas agree to
+        rounding (1e-7), and one broadcast of rank 0's tables at the END OF THE FIT makes them agree bit for bit, which is what the
+        blocking rule guarantees and what the callers of fit_distributed rely on."""
+        flag = self._late_apply()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.flat[:self._tail_at], src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        return flag
+
+    def exposed_exchange_ms(self, reset=True):
+        """(CUDA) milliseconds the rank's stream waited for reductions since the last call -- the part of the exchanges that was NOT hidden"""
+        ev = getattr(self, "late_wait_events", None) or []
+        if ev:
+            torch.cuda.synchronize(self.flat.device)
+        ms = [a.elapsed_time(b) for a, b in ev]
+        if reset and ev:
+            self.late_wait_events = []
+        return float(sum(ms)), len(ms)
+
     def all_reduce_deltas(self, group=None, average=False):
         """the exchange step: after it every rank holds epoch_start + sum (or mean) over ranks of its epoch's deltas"""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -318,8 +426,11 @@ class ShardedTrainer:
     `DeviceSession.run` (see make_device_trainer), in the CPU tests it is any stand-in with the same contract.
     """
 
-    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None):
+    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None, overlap=False):
         self.shared, self.epoch_fn, self.group, self.average = shared, epoch_fn, group, average
+        # overlap: the one-window-late merge (SharedTables.exchange_late) -- the all-reduce of a window's deltas runs beside the next
+        # window's SGD; needs the fused curvature rule, and finish() before the tables are read
+        self.overlap = bool(overlap)
         # exchanges per epoch: a number, or "auto" (the default of fit_distributed / bench.py) = AUTO_EXCHANGES per epoch during a fit's
         # first AUTO_EPOCHS epochs, one per epoch afterwards (exchanges_in_epoch).  Measured with the REAL engine in every shard
         # (tools/merge_engine_scan.py: eight shards of a config-2-shaped planted problem on one GPU, profiles/r04_notes.md): with one
@@ -353,6 +464,13 @@ class ShardedTrainer:
         if self.fused:
             s, n = self.user_norms_fn() if self.user_norms_fn is not None else (0.0, 0)
             eta = self.eta_fn(epoch) if (self.eta_fn is not None and epoch is not None) else None
+            if self.overlap:
+                flag = self.shared.exchange_late(self.group, s, n, failed=err is not None, eta=eta, window=window)
+                if err is not None:
+                    raise err                   # (its zero deltas and its flag are on their way: the peers' collective completes)
+                if float(flag) > 0:             # (read inside exchange_late already: no collective was launched behind it)
+                    raise RuntimeError("another rank's local epoch failed; stopping on every rank")
+                return
             flag = self.shared.exchange_fused(self.group, s, n, failed=err is not None, eta=eta, window=window)
             if err is not None:
                 raise err                       # (after the collective: the peers are not left waiting in it)
@@ -374,6 +492,17 @@ class ShardedTrainer:
         elif not self.average and hasattr(self.shared, "set_clamp_window"):
             self.shared.set_clamp_window(window)
         self.shared.all_reduce_deltas(self.group, self.average)
+
+    def finish(self):
+        """end of the fit: with the late merge, the final blocking exchange (the replicas are identical afterwards); a peer's failure
+        flagged in the last exchange is raised here"""
+        if self.fused and self.overlap:
+            flag = self.shared.finish_late(self.group)
+            if flag.is_cuda:
+                torch.cuda.synchronize(flag.device)
+            if float(flag) > 0:
+                raise RuntimeError("another rank's local epoch failed; stopping on every rank")
+        self.check_peers(synchronize=True)
 
     def check_peers(self, synchronize=False):
         """raise if the last fused exchange carried a peer's failure flag (GPU path; `synchronize` for the call after the LAST exchange)"""
@@ -452,7 +581,7 @@ def agree_on_merge_damping(shared, shard, group=None, merge_damping=None, syncs_
 
 
 def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=None,
-                        syncs_per_epoch=1, **session_kw):
+                        syncs_per_epoch=1, overlap=False, **session_kw):
     """wire a rank's shard to the HIP engine: weights are views into the flat bucket, so the engine's in-place
     atomics and the all-reduce act on the same memory"""
     from .engine import DeviceSession
@@ -463,7 +592,7 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
         def idle_epoch(_views, epoch, part=None):
             return dict(status=0, log_likelihood=np.zeros(1), reg_penalty=np.zeros(1), sgd_kernel_ms=np.zeros(1, np.float32),
                         n_draws=np.zeros(1, np.int64), epochs_done=1, launches_per_epoch=0, waves_per_launch=0)
-        return ShardedTrainer(shared, idle_epoch, group=group, average=average, syncs_per_epoch=syncs_per_epoch), None
+        return ShardedTrainer(shared, idle_epoch, group=group, average=average, syncs_per_epoch=syncs_per_epoch, overlap=overlap), None
     weights = dict(shared.views)
     weights["v_u"] = torch.as_tensor(shard["v_u"]).to(device)
     sess = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"],
@@ -486,16 +615,18 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
         return lr
 
     return ShardedTrainer(shared, epoch_fn, group=group, average=average, syncs_per_epoch=syncs_per_epoch, user_norms_fn=user_norms,
-                          eta_fn=eta_of), sess
+                          eta_fn=eta_of, overlap=overlap), sess
 
 
-def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per_epoch=1, seed=1492, c_factors=None, c_biases=None, **session_kw):
+def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per_epoch=1, seed=1492, c_factors=None, c_biases=None, late=False, **session_kw):
     """What `world` ranks would compute, on ONE GPU and in one process: `world` user shards, each trained by the REAL engine (its own
     DeviceSession, its own copy of the item-side tables, the concurrency plan a rank of that size gets), merged after every exchange
     window exactly like ShardedTrainer / SharedTables.exchange_fused merge the ranks -- curvature rule, rho from the mean |v_u|^2 of
     the previous exchange, per-item totals -- only with the all-reduce replaced by a loop.  A development and test tool (no 8-GPU node
     is needed to see what the merge rule does to the model when the shards are trained asynchronously); the shards run one after the
     other, so it says nothing about time.
+    `late`: the one-window-late merge (SharedTables.exchange_late) -- every shard trains window k + 1 on its OWN result of window k and
+    has its window-k delta replaced by the merged one afterwards; a final exchange makes the shards identical.
     problem: dict(interactions, sample_weight, csr_offsets, csr_items, x_uf, x_if, weights); returns the merged weights (numpy)."""
     U = len(problem["csr_offsets"]) - 1
     w = problem["weights"]
@@ -518,6 +649,15 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
     mean_vu2 = (torch.linalg.vector_norm(v0, dtype=torch.float64) ** 2 / max(v0.shape[0], 1))
     master = ref.flat[:T].clone()
     scale = torch.full((T,), 1.0 / world, dtype=torch.float32, device=device)
+    pending = None                # (late) the window whose "reduction" is in flight: (scale, total, own deltas, mean |v_u|^2 it reports)
+
+    def apply_pending():
+        nonlocal mean_vu2
+        p_scale, p_total, p_own, p_mean = pending
+        for r in range(world):
+            trainers[r].shared.flat[:T].add_(p_scale * p_total - p_own[r])
+        mean_vu2 = p_mean
+
     for e in range(epochs):
         n_x = (ShardedTrainer.AUTO_EXCHANGES if e < ShardedTrainer.AUTO_EPOCHS else 1) if syncs_per_epoch == "auto" else max(int(syncs_per_epoch), 1)
         for k in range(n_x):
@@ -527,14 +667,20 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
             t_v = torch.zeros(n_items, dtype=torch.float64, device=device)
             t_w = torch.zeros_like(t_v)
             sum_vu2, users = 0.0, 0
+            own = []
             for r in range(world):
                 tr, sess = trainers[r], sessions[r]
-                tr.shared.flat[:T].copy_(master)
+                if not late:
+                    tr.shared.flat[:T].copy_(master)
+                before = tr.shared.flat[:T].clone()
                 if sess is not None:
                     sess.run(epochs=1, epoch_begin=e, part=(k, n_x) if n_x > 1 else None)
                     sum_vu2 = sum_vu2 + torch.linalg.vector_norm(sess.weights["v_u"], dtype=torch.float64) ** 2
                     users += int(sess.weights["v_u"].shape[0])
-                total += tr.shared.flat[:T] - master
+                d = tr.shared.flat[:T] - before
+                total += d
+                if late:
+                    own.append(d)
                 t_v += (-torch.expm1(log_rho_v * (counts[r] / n_x))).to(torch.float32).to(torch.float64)
                 t_w += (-torch.expm1(log_rho_w * (counts[r] / n_x))).to(torch.float32).to(torch.float64)
             lo = 1.0 / world
@@ -544,8 +690,16 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
             scale[a:a + ref._sizes["v_i"]].view(n_items, F).copy_(sv.to(torch.float32)[:, None].expand(n_items, F))
             a = ref._starts["w_i"]
             scale[a:a + ref._sizes["w_i"]] = sb.to(torch.float32)
-            master = master + scale * total
-            mean_vu2 = sum_vu2 / max(users, 1)
+            if late:
+                if pending is not None:
+                    apply_pending()
+                pending = (scale.clone(), total, own, sum_vu2 / max(users, 1))
+            else:
+                master = master + scale * total
+                mean_vu2 = sum_vu2 / max(users, 1)
+    if late and pending is not None:
+        apply_pending()
+        master = trainers[0].shared.flat[:T].clone()
     out = {}
     ref.flat[:T].copy_(master)
     for name in SHARED_NAMES:
@@ -559,7 +713,7 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
 
 
 def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,
-                    group=None, device=None, merge_damping=None, syncs_per_epoch="auto", make_trainer=None):
+                    group=None, device=None, merge_damping=None, syncs_per_epoch="auto", make_trainer=None, overlap=True):
     """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
     the SAME arguments and the same numpy seed.
 
@@ -572,6 +726,10 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     mean |v_u|^2, no constant to choose); a number M = the clamp rule min(1, M / n_i) of earlier rounds.  `syncs_per_epoch`: exchanges
     of the item-side deltas per epoch -- "auto" (default): eight per epoch during the first eight epochs, when the model moves fastest
     and shards that do not hear from each other drift apart, one per epoch afterwards (ShardedTrainer); a number: that many, always.
+
+    `overlap` (default): the one-window-late merge -- the all-reduce of a window's deltas runs beside the next window's SGD and is
+    applied one window late, a final blocking exchange makes the replicas identical (SharedTables.exchange_late); False = every
+    exchange blocks (rounds 2-4).  Only the curvature rule overlaps.
 
     `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
     CPU tests; `finish()` must return the shard's trained v_u as a numpy array.
@@ -647,7 +805,7 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     if make_trainer is None:
         seed = int(np.random.randint(0, 2**31 - 1)) + rank if model.engine.seed is None else int(model.engine.seed) + rank
         trainer, sess = make_device_trainer(shard, tables, model.x_if, hyper, device, group=group, merge_damping=merge_damping,
-                                            syncs_per_epoch=syncs_per_epoch, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
+                                            syncs_per_epoch=syncs_per_epoch, overlap=overlap and merge_damping is None, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
                                             want_penalty=verbose, hogwild_damping=model.engine.damping,
                                             # every engine option of the single-GPU path applies to the shards as well
                                             debug_flags=int(model.engine.debug_flags), negative_stripes=model.engine.negative_stripes,
@@ -670,7 +828,7 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
             if rank == 0:
                 print("\ntraining epoch:", e)
                 print("log likelihood (un-penalised, all ranks):", round(float(ll.item()), 2))
-    trainer.check_peers(synchronize=True)     # (a peer's failure flagged in the LAST exchange)
+    trainer.finish()                          # (late merge: the final blocking exchange; a peer's failure flagged in the LAST exchange)
     # assemble the full model on every rank: item-side tables are already identical, user factors are all-gathered
     for k in SHARED_NAMES:
         getattr(model, k)[...] = trainer.shared.views[k].detach().cpu().numpy()

@@ -408,3 +408,167 @@ def test_curvature_rule_limits():
     np.testing.assert_allclose(sb.numpy(), [1.0, 0.25, 1.0, 1.0], atol=0.05)
     mid = curvature_scales(sum(curvature_terms(np.array([40.0]), log_rho) for _ in range(4)), log_rho, 4)[0].item()
     assert 0.3 < mid < 0.9            # 40 steps per rank at kappa = 0.02: between the sum and the average
+
+
+# ---- the one-window-late merge (round 5): SharedTables.exchange_late / ShardedTrainer(overlap=True) ----------------------------------
+LATE_WINDOWS, LATE_EPOCHS = 3, 2
+
+
+def _late_counts(rank, with_counts):
+    """item update counts of a rank per epoch: zero (every item-side scale is exactly 1, the feature tables' exactly 1 / world: the
+    whole merge is dyadic arithmetic and can be compared bit for bit) or a histogram (the curvature rule's scales: compared to 1e-6)"""
+    if not with_counts:
+        return np.zeros(I, np.float64)
+    rng = np.random.default_rng(50 + rank)
+    return rng.integers(0, 300, I).astype(np.float64) * (rng.random(I) < 0.8)
+
+
+def _late_delta(flat_tables, rank, step):
+    """what a rank's local window adds to ITS tables: a term that depends on the tables it trains on (so that training on one's own
+    un-merged result matters) and a rank / step pattern; every value a small multiple of 2^-12 -- sums and quarter-products stay exact"""
+    T = flat_tables.numel()
+    pattern = torch.as_tensor(((np.arange(T) * (rank + 3) + step * 7) % 17 - 8).astype(np.float32)) * 2.0 ** -9
+    return flat_tables * 0.25 + pattern
+
+
+def _late_initial(T):
+    return torch.as_tensor(((np.arange(T) * 5) % 13 - 6).astype(np.float32)) * 2.0 ** -6
+
+
+def _late_worker(rank, world, port, out_dir, with_counts):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, _, _, w = _problem()
+    shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+    T = shared._tail_at
+    shared.flat[:T] = _late_initial(T)
+    shared.set_merge_curvature(_late_counts(rank, with_counts), world, learning_rate=0.1, mean_vu2=0.4 + 0.1 * rank, n_users=7 + rank)
+    step = [0]
+
+    def fn(views, epoch, part=None):
+        shared.flat[:T] += _late_delta(shared.flat[:T].clone(), rank, step[0])
+        step[0] += 1
+        return dict(ll=np.zeros(1))
+    trainer = ShardedTrainer(shared, fn, syncs_per_epoch=LATE_WINDOWS, overlap=True,
+                             user_norms_fn=lambda: (float(2.0 + rank + step[0]), 7 + rank))
+    snaps = []
+    for e in range(LATE_EPOCHS):
+        trainer.run_epoch(e)
+        snaps.append(shared.flat[:T].numpy().copy())          # (between exchanges the replicas differ, by design)
+    trainer.finish()
+    np.savez(os.path.join(out_dir, "late%d.npz" % rank), final=shared.flat[:T].numpy(), snaps=np.stack(snaps))
+    dist.destroy_process_group()
+
+
+def _late_by_hand(world, with_counts):
+    """the blocking curvature rule with every merged delta applied ONE WINDOW LATE, rank by rank in one process"""
+    from rankfm_amd.distributed import curvature_log_rho
+    _, _, _, w = _problem()
+    ref = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+    T, n_items = ref._tail_at, ref._shapes["w_i"][0]
+    counts = [torch.as_tensor(_late_counts(r, with_counts)) for r in range(world)]
+    n_total = sum(counts)
+    tables = [_late_initial(T).clone() for _ in range(world)]
+    mean_vu2 = sum((0.4 + 0.1 * r) * (7 + r) for r in range(world)) / sum(7 + r for r in range(world))
+    pending = None            # (scale [T], SUM [T], own deltas per rank, sum |v_u|^2, users) of the window whose reduction is in flight
+    snaps, step = [[] for _ in range(world)], 0
+
+    def scale_of(mean):
+        log_rho = curvature_log_rho(0.1, SharedTables.CURVATURE_FACTORS, SharedTables.CURVATURE_BIASES, mean)
+        window = 1.0 / LATE_WINDOWS
+        scale = torch.full((T,), 1.0 / world, dtype=torch.float32)
+        for name, lr_ in (("v_i", log_rho[0]), ("w_i", log_rho[1])):
+            # (each rank's term is narrowed to float32 before the sum, like the bucket's tail)
+            t = sum((-torch.expm1(lr_ * (c * window))).to(torch.float32).to(torch.float64) for c in counts)
+            s = torch.where(t > 0, -torch.expm1(lr_ * (n_total * window)) / torch.clamp(t, min=1e-30), torch.ones_like(t)).clamp(1.0 / world, 1.0)
+            a = ref._starts[name]
+            per = ref._shapes["v_i"][1] if name == "v_i" else 1
+            scale[a:a + ref._sizes[name]] = s.to(torch.float32).repeat_interleave(per)
+        return scale
+
+    def apply(p):
+        nonlocal mean_vu2
+        scale, total, own, s_vu2, users = p
+        for r in range(world):
+            tables[r] = tables[r] + scale * total - own[r]
+        mean_vu2 = s_vu2 / users
+
+    for e in range(LATE_EPOCHS):
+        for k in range(LATE_WINDOWS):
+            own = []
+            for r in range(world):
+                d = _late_delta(tables[r], r, step)
+                tables[r] = tables[r] + d
+                own.append(d)
+            scale = scale_of(mean_vu2)                       # rho from the mean agreed at the last COMPLETED reduction
+            if pending is not None:
+                apply(pending)
+            total = own[0].clone()
+            for r in range(1, world):
+                total = total + own[r]
+            pending = (scale, total, own, sum(2.0 + r + step + 1 for r in range(world)), sum(7 + r for r in range(world)))
+            step += 1
+        for r in range(world):
+            snaps[r].append(tables[r].numpy().copy())
+    apply(pending)
+    return tables, snaps
+
+
+@pytest.mark.parametrize("world, with_counts", [(2, False), (8, False), (2, True)])
+def test_late_merge_is_the_blocking_rule_applied_one_window_late(tmp_path, world, with_counts):
+    """ShardedTrainer(overlap=True): the all-reduce of window k runs beside window k + 1 and is applied one window late
+    (SharedTables.exchange_late); after finish() the replicas are identical.  Against the same rule computed by hand, rank by rank:
+    bit for bit when every scale is a power of two (no item counts), to 2e-6 with the curvature rule's scales."""
+    mp.spawn(_late_worker, args=(world, _free_port(), str(tmp_path), with_counts), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("late%d.npz" % k)) for k in range(world)]
+    tables, snaps = _late_by_hand(world, with_counts)
+    for k in range(1, world):
+        assert np.array_equal(r[0]["final"], r[k]["final"])                       # identical replicas after the final exchange
+    assert not np.array_equal(r[0]["snaps"][0], r[1]["snaps"][0])                 # ... and different ones in between, by design
+    for k in range(world):
+        for e in range(LATE_EPOCHS):
+            if with_counts:
+                np.testing.assert_allclose(r[k]["snaps"][e], snaps[k][e], rtol=0, atol=2e-6)
+            else:
+                assert np.array_equal(r[k]["snaps"][e], snaps[k][e]), (k, e)
+        if with_counts:                          # (the replicas agree to rounding before the closing broadcast of rank 0's tables)
+            np.testing.assert_allclose(r[k]["final"], tables[0].numpy(), rtol=0, atol=2e-6)
+        else:
+            assert np.array_equal(r[k]["final"], tables[k].numpy())
+
+
+def _late_failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, _, _, w = _problem()
+    shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+    shared.set_merge_curvature(np.ones(I), world, learning_rate=0.1, mean_vu2=0.5, n_users=3)
+    calls = [0]
+
+    def fn(views, epoch, part=None):
+        calls[0] += 1
+        if rank == 1 and calls[0] == 2:
+            raise AssertionError("item factors [v_i] are not finite")
+        return dict(ll=np.zeros(1))
+    trainer = ShardedTrainer(shared, fn, syncs_per_epoch=4, overlap=True, user_norms_fn=lambda: (1.0, 3))
+    try:
+        trainer.run_epoch(0)
+        trainer.finish()
+        outcome = "no error"
+    except AssertionError as e:
+        outcome = "own: %s" % e
+    except RuntimeError as e:
+        outcome = "peer: %s (after %d windows)" % (e, calls[0])
+    with open(os.path.join(out_dir, "late_rank%d.txt" % rank), "w") as f:
+        f.write(outcome)
+    dist.destroy_process_group()
+
+
+def test_late_merge_a_failing_rank_stops_its_peers_one_window_later(tmp_path):
+    """the failure flag travels with the deltas: the peers see it when they wait for that window's reduction -- one window later --
+    and stop before they launch another collective the failed rank would never join"""
+    mp.spawn(_late_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (tmp_path / "late_rank0.txt").read_text(), (tmp_path / "late_rank1.txt").read_text()
+    assert r1.startswith("own: item factors") and r0.startswith("peer: another rank") and "after 3 windows" in r0, (r0, r1)

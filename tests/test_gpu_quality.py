@@ -213,8 +213,8 @@ def test_default_engine_holds_the_quality_bar_at_config2_shape(c2_shape_jobs, ta
     np.testing.assert_allclose(got[2], want[2], rtol=0.04)
 
 
-@pytest.mark.parametrize("syncs", ["auto"])
-def test_eight_engine_shards_merged_like_the_ranks_hold_the_quality_bar(c2_shape_jobs, syncs):
+@pytest.mark.parametrize("syncs, late", [("auto", True), ("auto", False)])
+def test_eight_engine_shards_merged_like_the_ranks_hold_the_quality_bar(c2_shape_jobs, syncs, late):
     """BASELINE configs 4 / 5 run on eight ranks.  No 8-GPU node: eight user shards of a config-2-shaped problem, each trained by the REAL
     engine on this one GPU (its own session, its own copy of the item-side tables, a rank's concurrency plan) and merged after every
     exchange like the ranks merge (distributed.emulate_ranks_on_one_device = the curvature rule of SharedTables.exchange_fused with the
@@ -223,7 +223,9 @@ def test_eight_engine_shards_merged_like_the_ranks_hold_the_quality_bar(c2_shape
     here (two seeds; the oracle fits are the fixture's), |v_i|, |w_i| within 5 %.  Measured (tools/merge_engine_scan.py,
     profiles/r04_notes.md): +0.2 point against one GPU on the whole data; with ONE exchange per epoch -13.9 after 5 epochs and +2.2
     after 15 -- which is why one exchange per epoch is not the default while the model moves fast.  (Round 3 tuned the rule against
-    shards trained by the sequential oracle; this closes the loop with the asynchronous engine in every shard.)"""
+    shards trained by the sequential oracle; this closes the loop with the asynchronous engine in every shard.)
+    `late` = the one-window-late merge, the default of fit_distributed since round 5 (the all-reduce of a window runs beside the next
+    window's SGD, SharedTables.exchange_late): the same bar; False = every exchange blocks (rounds 2-4)."""
     import torch
     from rankfm_amd import EngineOptions, RankFM, evaluation
     from rankfm_amd.distributed import emulate_ranks_on_one_device
@@ -240,7 +242,7 @@ def test_eight_engine_shards_merged_like_the_ranks_hold_the_quality_bar(c2_shape
                        x_uf=m.x_uf, x_if=m.x_if, weights={k: getattr(m, k) for k in ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")})
         hyper = dict(alpha=m.alpha, beta=m.beta, learning_rate=m.learning_rate, learning_schedule=m.learning_schedule,
                      learning_exponent=m.learning_exponent, max_samples=1)
-        out = emulate_ranks_on_one_device(problem, 8, hyper, C2_SHAPE["E"], torch.device("cuda", 0), syncs_per_epoch=syncs, seed=100 + seed)
+        out = emulate_ranks_on_one_device(problem, 8, hyper, C2_SHAPE["E"], torch.device("cuda", 0), syncs_per_epoch=syncs, seed=100 + seed, late=late)
         for side, weights in (("merged", out), ("oracle", pending[("bpr_k32", seed)].get(timeout=1500)["weights"])):
             o = RankFM(factors=F, loss=loss, engine=EngineOptions(seed=100 + seed))
             np.random.seed(seed)
@@ -252,7 +254,7 @@ def test_eight_engine_shards_merged_like_the_ranks_hold_the_quality_bar(c2_shape
             norms[side].append([np.linalg.norm(o.v_u), np.linalg.norm(o.v_i), np.linalg.norm(o.w_i)])
     mean = {k: float(np.mean(v)) for k, v in hits.items()}
     got, want = np.mean(norms["merged"], axis=0), np.mean(norms["oracle"], axis=0)
-    print("eight engine shards, %s exchange(s) per epoch: hit_rate@10 %s means %s  norms / oracle - 1 %s"
-          % (syncs, {k: np.round(v, 4).tolist() for k, v in hits.items()}, mean, np.round(got / want - 1.0, 4).tolist()))
+    print("eight engine shards, %s exchange(s) per epoch%s: hit_rate@10 %s means %s  norms / oracle - 1 %s"
+          % (syncs, ", late merge" if late else "", {k: np.round(v, 4).tolist() for k, v in hits.items()}, mean, np.round(got / want - 1.0, 4).tolist()))
     assert abs(mean["merged"] - mean["oracle"]) <= 0.010, mean
     np.testing.assert_allclose(got[1:], want[1:], rtol=0.05)
