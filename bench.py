@@ -199,7 +199,9 @@ def main():
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--syncs-per-epoch", default="auto", help="item-delta exchanges per epoch (N > 1): a number, or 'auto' = the production default "
                     "(8 per epoch during a fit's first 8 epochs, 1 afterwards: rankfm_amd.distributed.ShardedTrainer)")
-    ap.add_argument("--blocking-exchange", action="store_true", help="N > 1: every exchange blocks (rounds 2-4) instead of the one-window-late merge")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "late", "blocking"],
+                    help="N > 1: 'late' = the one-window-late merge (the all-reduce runs beside the next window's SGD, three times the cadence), "
+                         "'blocking' = every exchange blocks, 'auto' = decided after the first epoch from what an exchange and an epoch cost")
     ap.add_argument("--factors", type=int, default=0, help="override the config's factor count (experiments)")
     ap.add_argument("--shape", type=int, default=0, help="experiment: 1-based index into the kernel shape table")
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
@@ -278,7 +280,8 @@ def main():
                                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
                                         shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check,
                                         tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv},
-                                        negative_stripes=args.negative_stripes, overlap=world > 1 and not args.blocking_exchange)
+                                        negative_stripes=args.negative_stripes,
+                                        overlap=False if world == 1 else {"auto": "auto", "late": True, "blocking": False}[args.exchange])
     broadcast_from_rank0([trainer.shared.flat])
 
     def barrier():
@@ -395,7 +398,7 @@ def main():
                                          % (args.warmup, args.warmup + args.steps - 1) if args.syncs_per_epoch == "auto" else "")) if world > 1 else None,
                        # (N > 1) one all-reduce of the bucket by itself, and the stream time per epoch spent WAITING for exchanges
                        "exchange": ({"payload_bytes": trainer.shared.payload_bytes, "exchange_ms": exchange_ms,
-                                     "late_merge": not args.blocking_exchange,
+                                     "mode": args.exchange, "late_merge_in_use": bool(trainer.late), "decision": getattr(trainer, "overlap_decision", None),
                                      "exposed_exchange_ms_per_epoch": (exposed_ms / args.steps) if exposed_ms is not None else None,
                                      "waits_timed": n_exchanges} if world > 1 else None),
                        "sgd_launches_per_epoch": launches, "waves_per_launch": rep["waves_per_launch"],

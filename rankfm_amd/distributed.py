@@ -429,8 +429,9 @@ class ShardedTrainer:
     def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None, overlap=False):
         self.shared, self.epoch_fn, self.group, self.average = shared, epoch_fn, group, average
         # overlap: the one-window-late merge (SharedTables.exchange_late) -- the all-reduce of a window's deltas runs beside the next
-        # window's SGD; needs the fused curvature rule, and finish() before the tables are read
-        self.overlap = bool(overlap)
+        # window's SGD; needs the fused curvature rule, and finish() before the tables are read.  True / False / "auto" (decided after
+        # the first epoch from what an exchange and an epoch's SGD cost: _decide_overlap)
+        self.overlap = overlap if overlap == "auto" else bool(overlap)
         # exchanges per epoch: a number, or "auto" (the default of fit_distributed / bench.py) = AUTO_EXCHANGES per epoch during a fit's
         # first AUTO_EPOCHS epochs, one per epoch afterwards (exchanges_in_epoch).  Measured with the REAL engine in every shard
         # (tools/merge_engine_scan.py: eight shards of a config-2-shaped planted problem on one GPU, profiles/r04_notes.md): with one
@@ -452,26 +453,62 @@ class ShardedTrainer:
                 and getattr(self.shared, "_n_total", None) is not None)
 
     AUTO_EXCHANGES, AUTO_EPOCHS = 8, 8
+    # The late merge hears from the peers one window later, so it needs shorter windows for the same model: measured with the real engine
+    # in eight shards of a config-2-shaped problem (profiles/r05_notes.md; hit_rate@10 against the sequential oracle after 5 epochs):
+    # blocking, 8 windows per epoch -0.36 point; late, 8 / 12 / 16 / 24 windows -3.2 / -1.6 / -0.87 / -0.12.  Three times the cadence.
+    LATE_FACTOR = 3
+
+    @property
+    def late(self):
+        """is the one-window-late merge in use right now?  overlap True: always (with the fused curvature rule); "auto": after the first
+        epoch has measured what an exchange and an epoch's SGD cost on this job -- see _decide_overlap"""
+        return self.fused and (self.overlap is True or (self.overlap == "auto" and getattr(self, "_late_on", False)))
 
     def exchanges_in_epoch(self, epoch):
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return 1                              # (one rank: nothing to exchange, the epoch is one launch)
+        k = self.LATE_FACTOR if self.late else 1
         if self.syncs_per_epoch == "auto":
-            return self.AUTO_EXCHANGES if int(epoch) < self.AUTO_EPOCHS else 1
-        return max(1, int(self.syncs_per_epoch))
+            return k * (self.AUTO_EXCHANGES if int(epoch) < self.AUTO_EPOCHS else 1)
+        return max(1, int(self.syncs_per_epoch))          # (an explicit number is taken as it is, in either mode)
+
+    def _decide_overlap(self, sgd_ms, exchange_ms, n_blocking):
+        """overlap == "auto", after the first (blocking) epoch: the late merge hides its exchanges behind the SGD but needs LATE_FACTOR
+        times as many; with T = an epoch's SGD time, x = one exchange, n = the blocking cadence:
+            blocking  T + n x          late  max(T, LATE_FACTOR n x)
+        -- late wins when the exchanges fit behind the SGD, or still when (LATE_FACTOR - 1) n x < T.  A rank's share of config 5 (WARP,
+        k = 128: T = 246 ms, x ~ 3 ms over xGMI) overlaps; config 4's (T = 3.9 ms, x ~ 0.3 ms for 52 MB) does not.  Every rank must
+        decide alike: the maximum of the ranks' measurements is used."""
+        m = torch.tensor([float(sgd_ms), float(exchange_ms)], dtype=torch.float64, device=self.shared.flat.device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        T, x = float(m[0]), float(m[1])
+        n = max(1, int(n_blocking))
+        self._late_on = max(T, self.LATE_FACTOR * n * x) < T + n * x
+        self.overlap_decision = dict(sgd_ms_per_epoch=T, exchange_ms=x, blocking_windows=n, late=self._late_on)
 
     def _exchange(self, epoch=None, err=None, window=1.0):
         if self.fused:
             s, n = self.user_norms_fn() if self.user_norms_fn is not None else (0.0, 0)
             eta = self.eta_fn(epoch) if (self.eta_fn is not None and epoch is not None) else None
-            if self.overlap:
+            if self.late:
                 flag = self.shared.exchange_late(self.group, s, n, failed=err is not None, eta=eta, window=window)
                 if err is not None:
                     raise err                   # (its zero deltas and its flag are on their way: the peers' collective completes)
                 if float(flag) > 0:             # (read inside exchange_late already: no collective was launched behind it)
                     raise RuntimeError("another rank's local epoch failed; stopping on every rank")
                 return
+            timing = self.overlap == "auto" and not hasattr(self, "_late_on")
+            if timing:                          # (the first epoch of an "auto" job measures what one exchange costs)
+                import time
+                if self.shared.flat.is_cuda:
+                    torch.cuda.synchronize(self.shared.flat.device)
+                t0 = time.perf_counter()
             flag = self.shared.exchange_fused(self.group, s, n, failed=err is not None, eta=eta, window=window)
+            if timing:
+                if self.shared.flat.is_cuda:
+                    torch.cuda.synchronize(self.shared.flat.device)
+                self._exchange_ms = getattr(self, "_exchange_ms", []) + [(time.perf_counter() - t0) * 1e3]
             if err is not None:
                 raise err                       # (after the collective: the peers are not left waiting in it)
             # a PEER's failure: on CPU tensors the flag is read at once; on the GPU it is copied to pinned memory behind the exchange
@@ -496,7 +533,7 @@ class ShardedTrainer:
     def finish(self):
         """end of the fit: with the late merge, the final blocking exchange (the replicas are identical afterwards); a peer's failure
         flagged in the last exchange is raised here"""
-        if self.fused and self.overlap:
+        if self.fused and self.overlap and getattr(self.shared, "_late_own", None) is not None:
             flag = self.shared.finish_late(self.group)
             if flag.is_cuda:
                 torch.cuda.synchronize(flag.device)
@@ -536,6 +573,13 @@ class ShardedTrainer:
         return out, None
 
     def run_epoch(self, epoch):
+        out = self._run_epoch(epoch)
+        if self.overlap == "auto" and self.fused and not hasattr(self, "_late_on") and getattr(self, "_exchange_ms", None):
+            ms = out.get("sgd_kernel_ms") if isinstance(out, dict) else None
+            self._decide_overlap(float(np.sum(ms)) if ms is not None else 0.0, float(np.median(self._exchange_ms)), len(self._exchange_ms))
+        return out
+
+    def _run_epoch(self, epoch):
         # one epoch = `syncs_per_epoch` slices of the visiting order, each followed by the delta exchange
         n_x = self.exchanges_in_epoch(epoch)
         if n_x <= 1:
@@ -659,7 +703,7 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
         mean_vu2 = p_mean
 
     for e in range(epochs):
-        n_x = (ShardedTrainer.AUTO_EXCHANGES if e < ShardedTrainer.AUTO_EPOCHS else 1) if syncs_per_epoch == "auto" else max(int(syncs_per_epoch), 1)
+        n_x = ((ShardedTrainer.LATE_FACTOR if late else 1) * (ShardedTrainer.AUTO_EXCHANGES if e < ShardedTrainer.AUTO_EPOCHS else 1)) if syncs_per_epoch == "auto" else max(int(syncs_per_epoch), 1)
         for k in range(n_x):
             log_rho_v = torch.log1p(-torch.clamp(lr * c_v * mean_vu2, max=0.5))
             log_rho_w = float(np.log1p(-min(lr * c_w, 0.5)))
@@ -713,7 +757,7 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
 
 
 def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,
-                    group=None, device=None, merge_damping=None, syncs_per_epoch="auto", make_trainer=None, overlap=True):
+                    group=None, device=None, merge_damping=None, syncs_per_epoch="auto", make_trainer=None, overlap="auto"):
     """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
     the SAME arguments and the same numpy seed.
 
@@ -727,9 +771,11 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     of the item-side deltas per epoch -- "auto" (default): eight per epoch during the first eight epochs, when the model moves fastest
     and shards that do not hear from each other drift apart, one per epoch afterwards (ShardedTrainer); a number: that many, always.
 
-    `overlap` (default): the one-window-late merge -- the all-reduce of a window's deltas runs beside the next window's SGD and is
-    applied one window late, a final blocking exchange makes the replicas identical (SharedTables.exchange_late); False = every
-    exchange blocks (rounds 2-4).  Only the curvature rule overlaps.
+    `overlap`: True = the one-window-late merge -- the all-reduce of a window's deltas runs beside the next window's SGD and is applied
+    one window late, a final blocking exchange makes the replicas identical (SharedTables.exchange_late); it hears from the peers a
+    window later and therefore runs three times the cadence (ShardedTrainer.LATE_FACTOR, measured).  False = every exchange blocks
+    (rounds 2-4).  "auto" (default): the first epoch blocks and measures; the late merge is taken from the second epoch on when it
+    is the faster of the two on this job (ShardedTrainer._decide_overlap).  Only the curvature rule overlaps.
 
     `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
     CPU tests; `finish()` must return the shard's trained v_u as a numpy array.
@@ -805,7 +851,7 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     if make_trainer is None:
         seed = int(np.random.randint(0, 2**31 - 1)) + rank if model.engine.seed is None else int(model.engine.seed) + rank
         trainer, sess = make_device_trainer(shard, tables, model.x_if, hyper, device, group=group, merge_damping=merge_damping,
-                                            syncs_per_epoch=syncs_per_epoch, overlap=overlap and merge_damping is None, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
+                                            syncs_per_epoch=syncs_per_epoch, overlap=overlap if merge_damping is None else False, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
                                             want_penalty=verbose, hogwild_damping=model.engine.damping,
                                             # every engine option of the single-GPU path applies to the shards as well
                                             debug_flags=int(model.engine.debug_flags), negative_stripes=model.engine.negative_stripes,

@@ -572,3 +572,18 @@ def test_late_merge_a_failing_rank_stops_its_peers_one_window_later(tmp_path):
     mp.spawn(_late_failing_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (tmp_path / "late_rank0.txt").read_text(), (tmp_path / "late_rank1.txt").read_text()
     assert r1.startswith("own: item factors") and r0.startswith("peer: another rank") and "after 3 windows" in r0, (r0, r1)
+
+
+def test_auto_overlap_takes_the_late_merge_only_where_it_is_faster():
+    """ShardedTrainer(overlap="auto") decides after its first (blocking) epoch: blocking costs T + n x per epoch, the late merge
+    max(T, 3 n x) -- config 5's share (246 ms of SGD, ~3 ms per exchange) overlaps, config 4's (3.9 ms, ~0.3 ms) does not"""
+    _, _, _, w = _problem()
+    shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+    t = ShardedTrainer(shared, lambda views, epoch, part=None: dict(ll=np.zeros(1)), overlap="auto")
+    t._decide_overlap(246.0, 3.0, 8)
+    assert t._late_on and t.overlap_decision["late"]
+    t._decide_overlap(3.9, 0.3, 8)
+    assert not t._late_on
+    t._decide_overlap(3.9, 0.3, 1)              # (one exchange per epoch: 0.9 ms of reductions fit behind 3.9 ms of SGD)
+    assert t._late_on
+    assert not t.late                           # (no curvature rule armed on one process: nothing to overlap)
