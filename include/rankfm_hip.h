@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RFM_ABI_VERSION 4
+#define RFM_ABI_VERSION 5
 
 typedef enum rfm_status {
     RFM_OK = 0,
@@ -139,6 +139,10 @@ typedef struct rfm_fit_config {
     int32_t tune_table_every;      /* features kernel: the table trainer applies rows-of-the-launch / this many staged steps per launch
                                       (auto: 2.4 x the launch's row groups / 64 -- every 446th row on a full chip -- on launches of at least
                                       4096 row groups, 1.8 x on smaller ones and in the opening launch: an empirical optimum) */
+    int32_t tune_table_step_pct;   /* features kernel: the table trainer's step length in percent of the epoch's learning rate (auto: 100;
+                                      experiments -- the trainer applies batches of staged steps that were scored on one table state, and a
+                                      shorter step is the lever against the noise that adds: DESIGN.md 3.3) */
+    int32_t reserved_pad;          /* (keeps the struct's size a multiple of 8) */
 } rfm_fit_config;
 
 /* All pointers of one struct live in the same memory space: device memory for the *_device entry

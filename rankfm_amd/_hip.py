@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankfm_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK = 0
 ERR_BAD_ARG, ERR_UNKNOWN_SCHEDULE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_USER_SATURATED, ERR_WORKSPACE = (
     -1, -2, -3, -4, -5, -6, -7)
@@ -39,12 +39,12 @@ class FitConfig(C.Structure):
         ("plan_token", C.c_int64),
         ("tune_segment_rows", C.c_int32), ("tune_stripe_window", C.c_int32), ("tune_stripe_rows", C.c_int32),
         ("tune_hot_publications", C.c_int32), ("tune_feature_waves", C.c_int32), ("tune_table_producers", C.c_int32),
-        ("sampler", C.c_int32), ("tune_table_every", C.c_int32),
+        ("sampler", C.c_int32), ("tune_table_every", C.c_int32), ("tune_table_step_pct", C.c_int32), ("reserved_pad", C.c_int32),
     ]
 
 
 #: names of the geometry overrides of rfm_fit_config (0 = automatic); EngineOptions.tune / DeviceSession(tune=...) carry them
-TUNE_FIELDS = ("segment_rows", "stripe_window", "stripe_rows", "hot_publications", "feature_waves", "table_producers", "table_every")
+TUNE_FIELDS = ("segment_rows", "stripe_window", "stripe_rows", "hot_publications", "feature_waves", "table_producers", "table_every", "table_step_pct")
 
 
 def tune_kwargs(tune):

@@ -225,6 +225,16 @@ constexpr int kMaxHot = 64;                      // hot-row accumulator slots pe
 // epoch 1 / 2 log-likelihood, |w_i|, kernel): 48: +0.40 % / -0.04 %, +0.25 %, 2.67 ms; 32: +0.55 % / -0.05 %, +0.36 %, 2.58 ms;
 // 24: +0.73 % / -0.07 %, +0.50 %, 2.52 ms; 16: +1.08 % / -0.10 %, +0.75 %, 2.49 ms.  32 keeps half the parity bound (1 %) as margin.
 constexpr double kHotPublications = 32.0;
+// Table trainer quota on chip-filling launches: every (kTableQuotaFactor x row groups / 64)-th row -- the 446th on a full chip.  Round 4
+// found ranking quality a HUMP in it (denser: the trainer ran to the launch's end and cost the rows their quiet period, -3.8 points of
+// hit_rate@10 at every 250th row; sparser: -1.2 at the 600th).  Since round 5 the trainer stops by itself once 80 % of the launch's
+// segments are handed out (kTableQuietFrom, rfm_sgd_features.hpp) and the dense side is flat -- config-2 shape with tags, three seeds x
+// two runs against the oracle's 0.3792: every 123rd / 223rd / 246th / 300th row -0.34 / -0.29 / -0.10 / -0.29 point, 446th -0.77 ...
+// -0.17 (two runs of the sweep), 491st -0.17, 650th -1.2, 892nd -1.4 (profiles/r05_notes.md section 8).  A denser default (1.3 x, every
+// 246th row) was measured too: flat from x 0.5 to x 2 at that shape, but on config 4's share -- 32 + 32 tags without signal, learning
+// rate 0.03 -- the tables' norms leave the oracle's (first epoch |w_if| +47 %, |v_if| +18 %, |w_i| +2.7 % against -9 %, +4.5 %, -1.1 %
+// at 2.4 x), so 2.4 x stays: the tables track the oracle's to 10 % there, and the sparse side (x 2) remains the open end of row a6.
+constexpr double kTableQuotaFactor = 2.4;
 
 constexpr int kStripeSegmentRows = 16;         // segments of a plan that uses negative stripes (see rfm_fit_device, "segment length")
 // (a user of degree d is cut into ceil(d / rows) <= d / rows + 1 segments)
@@ -288,6 +298,9 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
 // full factor rows of 16-lane row groups (k = 16, 32, 48, 64, 96, 128); debug_flags bit 9 keeps the rows row-major (experiments)
 static bool vi_split_eligible(const rfm_fit_config *c) {
     const ShapeEntry *sh = pick_shape(c->n_factors);
+    // (Models with features stay row-major: measured on config 4's share, the pipelined feature row loop on segment-major rows runs
+    //  4.12 against 3.82 - 3.85 ms -- it is bound by its 168 registers and its latency chain, not by the atomic path, and the
+    //  per-segment addresses cost it two spills: profiles/r05_notes.md.  WARP reads ~23 candidate rows per update: row-major too.)
     return sh && sh->group == 16 && c->n_factors == sh->group * sh->kpl && c->max_samples == 1 && !c->has_user_features && !c->has_item_features &&
            c->mode == RFM_MODE_HOGWILD && c->sampler == RFM_SAMPLER_UNIFORM && !(c->debug_flags & 512);
 }
@@ -310,7 +323,7 @@ static int validate(const rfm_fit_config *c) {
     if (c->tune_segment_rows < 0 || c->tune_segment_rows > kSegmentRows || c->tune_stripe_window < 0 || c->tune_stripe_window > 4096 ||
         c->tune_stripe_rows < -1 || c->tune_stripe_rows > 4096 || c->tune_hot_publications < 0 || c->tune_hot_publications > 65536 ||
         c->tune_feature_waves < 0 || c->tune_feature_waves > 16 || c->tune_table_producers < 0 || c->tune_table_producers > kFeatMaxProducers ||
-        c->tune_table_every < 0 ||
+        c->tune_table_every < 0 || c->tune_table_step_pct < 0 || c->tune_table_step_pct > 400 ||
         (c->sampler != RFM_SAMPLER_UNIFORM && c->sampler != RFM_SAMPLER_STRIPES))
         return RFM_ERR_BAD_ARG;
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
@@ -772,6 +785,12 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // weights that are stale by up to that many steps, and Hogwild only tracks sequential SGD while that window is
         // a small fraction of the data (DESIGN.md "staleness").
         int64_t cap = (int64_t)(g_sm_count > 0 ? g_sm_count : 256) * 16 / waves_per_block;
+        // BPR with hot-row accumulators (config 2's kernel): three quarters of the CUs.  The kernel sits at the memory-side atomic
+        // path's capacity, not at the CUs': measured in round 5 (three interleaved sessions each, profiles/r05_notes.md) 192 workgroups
+        // run 2.61 / 2.63 / 2.60 ms against 2.63 / 2.66 / 2.66 at 256 (224: 2.64 / 2.66 / 2.61; 160 and fewer: slower), with a quarter
+        // fewer rows in flight -- the asynchrony term of the ranking quality scales with those (-1.9 point at 16 k in
+        // flight against the oracle in the engine's order, -1.2 at 12 k) -- and a quarter fewer hot-row publications.
+        if (use_hot && !feat && cfg->max_samples == 1 && cfg->n_workgroups <= 0) cap = cap * 3 / 4;
         // (feature launches: ONE workgroup per CU whatever its size -- the 12-wavefront row loop takes three wavefronts per SIMD and no
         //  second workgroup fits beside it; the trainer, its producers and the row loops must all be resident)
         if (use_segments && feat) cap = std::min<int64_t>(cap, g_sm_count > 0 ? g_sm_count : 256);
@@ -970,17 +989,18 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         a.feat_clock = ws.feat_clock;
         a.sclk = ws.sclk;
         a.table_quota = 0;
+        a.table_step = cfg->tune_table_step_pct > 0 ? (float)cfg->tune_table_step_pct * 0.01f : 1.0f;
+        a.reserved_pad = 0;
         // table trainer: steps to apply in a launch of `n_units` segments beside `rowloop_wgs` row-loop workgroups.  A row-loop workgroup
         // walks about as many rows per second as the trainer applies steps (profiles/r03_notes.md section 7), so a trainer that works
         // flat out for the length of the launch gets through rows / workgroups of them; measured on config 4's share with the split
         // kernels: 5.8 steps/us against 1450 rows/us of 252 x 48 row groups, i.e. every 250th row in equal time.  The quota is that
-        // pace with a wide margin: every (2.4 x row groups / 64)-th row -- 446 on the full chip; the opening launch keeps 1.8 x: every 22nd --
-        // or the caller's `tune_table_every`.  Why 2.4 and not the 1.8 of a trainer that "just finishes first": the rows of an epoch's last
-        // part, which train against tables that have STOPPED moving, are what brings the engine's tables (noisier than the reference's:
-        // 64 staged steps scored on one table state) to the reference's ranking quality, and a tables kernel that runs as long as the row
-        // loops leaves none (profiles/r04_notes.md section 11; config-2 shape with tags, three seeds: every 250th row -3.8 points of
-        // hit_rate@10, 290th -0.4, 335th -0.3 ... -0.8 depending on the build, 400th - 450th -0.1, 600th -1.2; at config 4's shape, where
-        // the 335th row put the tables kernel at 0.94 of the row loops' time, the 450th ranks 1.6 points better).  Launches that do
+        // pace with a wide margin: every (kTableQuotaFactor x row groups / 64)-th row -- 446 on the full chip; the opening launch keeps
+        // 1.8 x: every 22nd -- or the caller's `tune_table_every`.  The rows of a launch's last part, which train against tables that have
+        // STOPPED moving, are what brings the engine's tables (64 staged steps scored on one table state) to the reference's ranking
+        // quality (profiles/r04_notes.md section 11); the quota's margin secures that quiet period, and since round 5 the trainer also
+        // stops by itself at 80 % of the launch's segments (kTableQuietFrom), so that a denser quota (`tune_table_every`) can no longer
+        // run to the launch's end and beyond.  Launches that do
         // not fill a good part of the chip (fewer than 4096 row groups) keep 1.8: their row loops are latency-bound and slow per row, the
         // trainer is nowhere near their length, and the 3000 x 2000 feature fixture sits within 0.3 point of the REFERENCE there (2.4
         // ranks it a full point ABOVE the reference -- outside the bar from the other side).
@@ -1056,7 +1076,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
             a.tickets = tickets_of(window);
-            if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, 2.4);
+            if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, kTableQuotaFactor);
             launch(a, grid, stream);
         }
         if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);

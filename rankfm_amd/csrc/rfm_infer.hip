@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "../../include/rankfm_hip.h"
 
 namespace rfm {
@@ -344,6 +346,175 @@ __global__ void __launch_bounds__(256) topn_select_kernel(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// `_recommend` WITHOUT the score matrix (round 5).  The two-pass threshold selection above reads a [users, items]
+// matrix twice that the GEMM has just written (1.4 GB for 9,936 users x 35 k items); the only thing its first pass needs of it are
+// per-segment maxima, and those can come straight out of the accumulators:
+//   seen_mask_kernel        one bit per (user slot, item): the user's observed items (rankfm/_rankfm.pyx:450-451), from the CSR lists
+//   scores_blockmax_kernel  the scoring GEMM with the ROLES SWAPPED -- items are the rows of the 32 x 32 accumulator, users its columns --
+//                           so that a lane holds sixteen items of ONE user: the best of a block of 32 items is fifteen compares in
+//                           registers and one exchange with lane ^ 32 instead of a five-step shuffle reduction per row; it writes the
+//                           best (score, item) of every (block of 32 items, user), observed items and NaN excluded, and nothing else
+//   select_blocks_kernel    one workgroup per user: the n_rec-th best block maximum is a lower bound of the top n_rec (at least n_rec
+//                           items rank at or above it); the blocks whose maximum reaches it -- n_rec of them, a few more under ties --
+//                           are scored again (<= a few hundred dot products), and n_rec rounds of argmax give the ranking.
+// Same ordering rules as topn_select_kernel (descending utility, among equals the larger index first, NaN never wins, observed items
+// out; equal scores may come out in any order in the reference too: np.argsort is unstable, rankfm/_rankfm.pyx:444).  The re-scored
+// candidates are fp32 FMA chains like the matrix cores' (v_mfma_f32_32x32x2_f32 is exact fp32), so the ranking is the scores' own.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlk = 32;                          // items per block maximum: the rows of one wavefront's accumulator
+constexpr int kMaxCandBlocks = kCands / kBlk;     // candidate blocks a user can hold in LDS (128)
+
+__global__ void __launch_bounds__(256) seen_mask_kernel(const float *__restrict__ users, long long user_begin, const int64_t *__restrict__ csr_off,
+                                                       const int32_t *__restrict__ csr_items, int n_words, unsigned *__restrict__ mask) {
+    const long long slot = blockIdx.x;
+    const float uf = users[user_begin + slot];
+    if (isnan(uf)) return;
+    const int u = (int)uf;
+    unsigned *row = mask + (size_t)slot * n_words;
+    for (int64_t k = csr_off[u] + threadIdx.x; k < csr_off[u + 1]; k += blockDim.x) {
+        const int it = csr_items[k];
+        atomicOr(row + (it >> 5), 1u << (it & 31));
+    }
+}
+
+__global__ void __launch_bounds__(256) scores_blockmax_kernel(const float *__restrict__ ueff, const float *__restrict__ veff,
+                                                             const float *__restrict__ bias, const unsigned *__restrict__ mask, int n_slots,
+                                                             int n_items, int kp, int n_words, float *__restrict__ bmax_val,
+                                                             int *__restrict__ bmax_idx) {
+    __shared__ float sA[64 * kLd], sB[64 * kLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;                 // item half / user half of the 64 x 64 tile
+    const int item0 = blockIdx.x * 64, slot0 = blockIdx.y * 64;
+    f32x16 acc = {0};
+    for (int k0 = 0; k0 < kp; k0 += kKT) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int e = tid + 256 * r, row = e >> 5, col = e & 31;
+            const int it = item0 + row, s = slot0 + row;
+            sA[row * kLd + col] = it < n_items ? veff[(size_t)it * kp + k0 + col] : 0.0f;
+            sB[row * kLd + col] = s < n_slots ? ueff[(size_t)s * kp + k0 + col] : 0.0f;
+        }
+        __syncthreads();
+        // A operand (items): lane l holds A[row = l & 31][k = l >> 5]; B operand (users): lane l holds B[k = l >> 5][col = l & 31]
+        const float *pa = sA + (wr * 32 + (lane & 31)) * kLd + (lane >> 5);
+        const float *pb = sB + (wc * 32 + (lane & 31)) * kLd + (lane >> 5);
+#pragma unroll
+        for (int k = 0; k < kKT; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+        __syncthreads();
+    }
+    // accumulator register r of lane l: item row (r & 3) + 8 (r >> 2) + 4 (l >> 5), user column l & 31
+    const int slot = slot0 + wc * 32 + (lane & 31);
+    const int blk = (item0 >> 5) + wr;
+    const bool live = slot < n_slots && blk < n_words;
+    const unsigned seen = (live && mask) ? mask[(size_t)slot * n_words + blk] : 0u;
+    float bv = -INFINITY;
+    int bi = -1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int it = item0 + wr * 32 + row;
+        if (live && it < n_items && !((seen >> row) & 1u)) {
+            const float v = acc[r] + bias[it];
+            if (v > -INFINITY && (bi < 0 || ranks_before(v, it, bv, bi))) { bv = v; bi = it; }
+        }
+    }
+    const float ov = __shfl_xor(bv, 32);
+    const int oi = __shfl_xor(bi, 32);
+    if (oi >= 0 && (bi < 0 || ranks_before(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    if (live && lane < 32) {
+        bmax_val[(size_t)blk * n_slots + slot] = bv;
+        bmax_idx[(size_t)blk * n_slots + slot] = bi;
+    }
+}
+
+__global__ void __launch_bounds__(256) select_blocks_kernel(const float *__restrict__ users, long long user_begin, int n_slots, int n_items, int kp,
+                                                           const float *__restrict__ ueff, const float *__restrict__ veff,
+                                                           const float *__restrict__ bias, const unsigned *__restrict__ mask, int n_words,
+                                                           const float *__restrict__ bmax_val, const int *__restrict__ bmax_idx, int n_rec,
+                                                           float *__restrict__ rec) {
+    __shared__ float s_val[kSegs];          // block maxima, then the candidates
+    __shared__ int s_idx[kSegs];
+    __shared__ int s_blk[kMaxCandBlocks];
+    __shared__ float s_u[512];              // the user's effective factor row (kp <= 512)
+    __shared__ float w_val[4];
+    __shared__ int w_idx[4];
+    __shared__ int n_cand, n_blk;
+    const int slot = blockIdx.x;
+    const float uf = users[user_begin + slot];
+    float *out = rec + (size_t)(user_begin + slot) * n_rec;
+    if (isnan(uf)) {                                                      // rankfm/_rankfm.pyx:435-437
+        for (int k = threadIdx.x; k < n_rec; k += blockDim.x) out[k] = __uint_as_float(0x7fc00000u);
+        return;
+    }
+    for (int b = threadIdx.x; b < n_words; b += blockDim.x) {
+        s_val[b] = bmax_val[(size_t)b * n_slots + slot];
+        s_idx[b] = bmax_idx[(size_t)b * n_slots + slot];
+    }
+    for (int k = threadIdx.x; k < kp; k += blockDim.x) s_u[k] = ueff[(size_t)slot * kp + k];
+    if (threadIdx.x == 0) { n_cand = 0; n_blk = 0; }
+    __syncthreads();
+    // the n_rec-th best block maximum (selected maxima are struck out of the LDS copy: index -> -2 - index, so that they can be told from
+    // blocks without a rankable item, -1)
+    float tv = -INFINITY;
+    int ti = -1;
+    bool take_all = false;      // fewer than n_rec blocks hold a rankable item: every rankable item of those blocks is a candidate
+    for (int r = 0; r < n_rec; ++r) {
+        float bv = -INFINITY;
+        int bi = -1, bs = -1;
+        for (int b = threadIdx.x; b < n_words; b += blockDim.x)
+            if (s_idx[b] >= 0 && (bi < 0 || ranks_before(s_val[b], s_idx[b], bv, bi))) { bv = s_val[b]; bi = s_idx[b]; bs = b; }
+        float gv = bv;
+        int gi = bi;
+        block_best(gv, gi, w_val, w_idx);
+        if (gi < 0) { take_all = true; break; }
+        tv = gv; ti = gi;
+        if (bi == gi && bs >= 0) s_idx[bs] = -2 - s_idx[bs];
+        __syncthreads();
+    }
+    __syncthreads();
+    // candidate blocks: every block whose maximum ranks at or above the threshold (the struck-out ones, and ties with the last of them)
+    for (int b = threadIdx.x; b < n_words; b += blockDim.x) {
+        const int raw = s_idx[b];
+        const int idx = raw <= -2 ? -2 - raw : raw;
+        if (idx < 0) continue;
+        if (take_all || raw <= -2 || idx == ti || ranks_before(s_val[b], idx, tv, ti)) {
+            const int c = atomicAdd(&n_blk, 1);
+            if (c < kMaxCandBlocks) s_blk[c] = b;
+        }
+    }
+    __syncthreads();
+    const int nb = n_blk < kMaxCandBlocks ? n_blk : kMaxCandBlocks;
+    __syncthreads();
+    // score the candidate blocks' items again: bias + the fp32 FMA chain over the padded factor row, observed items and NaN left out
+    for (int e = threadIdx.x; e < nb * kBlk; e += blockDim.x) {
+        const int b = s_blk[e / kBlk], it = b * kBlk + (e % kBlk);
+        if (it >= n_items) continue;
+        if (mask && ((mask[(size_t)slot * n_words + b] >> (it & 31)) & 1u)) continue;
+        const float *vr = veff + (size_t)it * kp;
+        float acc = 0.0f;
+        for (int k = 0; k < kp; ++k) acc = fmaf(vr[k], s_u[k], acc);
+        const float v = acc + bias[it];
+        if (!(v > -INFINITY)) continue;
+        const int c = atomicAdd(&n_cand, 1);
+        s_val[c] = v; s_idx[c] = it;                  // (nb * kBlk <= kCands = kSegs entries)
+    }
+    __syncthreads();
+    const int nc = n_cand;
+    for (int r = 0; r < n_rec; ++r) {
+        float bv = -INFINITY;
+        int bi = -1, bc = -1;
+        for (int c = threadIdx.x; c < nc; c += blockDim.x)
+            if (s_idx[c] >= 0 && (bi < 0 || ranks_before(s_val[c], s_idx[c], bv, bi))) { bv = s_val[c]; bi = s_idx[c]; bc = c; }
+        float gv = bv;
+        int gi = bi;
+        block_best(gv, gi, w_val, w_idx);
+        if (threadIdx.x == 0) out[r] = gi >= 0 ? (float)gi : __uint_as_float(0x7fc00000u);
+        if (gi >= 0 && bi == gi && bc >= 0) s_idx[bc] = -1;
+        __syncthreads();
+    }
+}
+
 // similar_items / similar_users (rankfm/rankfm.py:405-454): latent representation rep[r] = v[r] + x[r] . v_f of every row, its
 // dot product with the query row's representation -> sims [n_rows]; the ranking is topn_select_kernel with the query skipped.
 __global__ void __launch_bounds__(256) similarity_kernel(const float *__restrict__ v, const float *__restrict__ x, const float *__restrict__ vf,
@@ -401,6 +572,7 @@ static void free_all(void **p, int n) {
 }
 
 constexpr long long kRecommendChunk = 1024;   // users scored per pass (workspace = chunk * n_items floats)
+constexpr long long kFusedChunk = 16384;      // users per pass of the matrix-free path (select_blocks_kernel)
 
 }  // namespace rfm
 
@@ -471,6 +643,38 @@ int rfm_recommend_device(const rfm_model_view *m, int64_t n_users, const float *
     float *bias = veff + up256(I * kp);
     float *ueff = bias + up256(I);
     build_veff_kernel<<<dim3(512), dim3(256), 0, stream>>>(*m, kp, veff, bias);
+    // The usual case -- a short list out of a catalogue of up to 131,072 items -- never writes the score matrix: block maxima out of
+    // the GEMM's accumulators, then the few candidate blocks scored again (select_blocks_kernel).  The `scores` area of the workspace
+    // (chunk x I floats) holds, for a chunk of up to kFusedChunk users, the maxima (8 bytes per block of 32 items and user), the
+    // observed-item bits (4 bytes) and the users' effective factor rows.
+    const int n_words = (m->n_items + kBlk - 1) / kBlk;
+    if (n_rec <= kTopLocal && n_words <= kSegs && kp <= 512) {
+        // (12 n_words + 4 kp bytes per user out of 4 x 1024 x I: a chunk of at least 8 x 1024 users always fits)
+        const size_t per_user = 12 * (size_t)n_words + 4 * (size_t)kp + 16;
+        long long fchunk = (long long)(((size_t)chunk * I * sizeof(float)) / per_user);
+        fchunk = std::min<long long>(std::min<long long>(fchunk, kFusedChunk), n_users);
+        if (fchunk >= 1 && (fchunk >= n_users || fchunk >= 64)) {
+            if (fchunk < n_users) fchunk &= ~63LL;
+            float *bmax_val = scores;
+            int *bmax_idx = (int *)(bmax_val + up256((size_t)n_words * fchunk));
+            unsigned *mask = (unsigned *)(bmax_idx + up256((size_t)n_words * fchunk));
+            float *ueff_f = (float *)(mask + up256((size_t)n_words * fchunk));
+            for (long long u0 = 0; u0 < n_users; u0 += fchunk) {
+                const long long nu = (n_users - u0) < fchunk ? (n_users - u0) : fchunk;
+                build_ueff_kernel<<<dim3(256), dim3(256), 0, stream>>>(*m, users, u0, (int)nu, kp, ueff_f);
+                if (filter_previous) {
+                    if (hipMemsetAsync(mask, 0, sizeof(unsigned) * (size_t)n_words * nu, stream) != hipSuccess) return RFM_ERR_HIP;
+                    seen_mask_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, csr_off, csr_items, n_words, mask);
+                }
+                scores_blockmax_kernel<<<dim3((unsigned)((I + 63) / 64), (unsigned)((nu + 63) / 64)), dim3(256), 0, stream>>>(
+                    ueff_f, veff, bias, filter_previous ? mask : nullptr, (int)nu, m->n_items, kp, n_words, bmax_val, bmax_idx);
+                select_blocks_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, (int)nu, m->n_items, kp, ueff_f, veff, bias,
+                                                                                    filter_previous ? mask : nullptr, n_words, bmax_val,
+                                                                                    bmax_idx, n_rec, rec);
+            }
+            return hipGetLastError() == hipSuccess ? RFM_OK : RFM_ERR_HIP;
+        }
+    }
     for (long long u0 = 0; u0 < n_users; u0 += chunk) {
         const long long nu = (n_users - u0) < chunk ? (n_users - u0) : chunk;
         build_ueff_kernel<<<dim3(64), dim3(256), 0, stream>>>(*m, users, u0, (int)nu, kp, ueff);

@@ -157,11 +157,12 @@ def test_config4_one_gpu_share_with_features_tracks_sequential_oracle(oracle):
     assert abs(r1["w_i"] - 1.0) <= 0.025 and abs(r1["v_u"] - 1.0) <= 0.01 and abs(r1["v_i"] - 1.0) <= 0.01, r1
     np.testing.assert_allclose(rep2["log_likelihood"], out2["ll64"], rtol=0.01)
     assert all(abs(r2[k] - 1.0) <= 0.015 for k in ("w_i", "v_u", "v_i")), r2
-    # the feature tables: |v_uf|, |v_if| within 20 % (measured 0.934 ... 0.938 / 1.118 ... 1.120 after the first epoch, 1.139 ... 1.142 /
-    # 0.931 ... 0.932 after the second, three runs: with the trainer's fixed quota they repeat to half a percent); |w_if| -- 32 numbers
-    # with a memory of ~170 steps -- within 0.6 ... 1.6 (measured 1.20 ... 1.21)
+    # the feature tables: |v_uf|, |v_if| within 10 %, |w_if| -- 32 numbers with a memory of ~170 steps -- within 15 % (VERDICT r04 item 2's
+    # bounds).  Measured in round 5 (three runs on two builds, profiles/r05_notes.md section 8): after the first epoch 1.044 ... 1.045 /
+    # 1.045 / 0.908, after the second 1.000 ... 1.002 / 0.923 ... 0.927 / 1.072 ... 1.086 (round 4's notes had 0.93 / 1.12 and 1.14 /
+    # 0.93 / 1.20 under the first quota rule); with the trainer's fixed quota they repeat to half a percent.
     for r in (r1, r2):
-        assert all(abs(r[k] - 1.0) <= 0.20 for k in ("v_uf", "v_if")) and 0.6 < r["w_if"] < 1.6, r
+        assert all(abs(r[k] - 1.0) <= 0.10 for k in ("v_uf", "v_if")) and abs(r["w_if"] - 1.0) <= 0.15, r
     assert all(np.isfinite(g2[k]).all() for k in g2)
 
 

@@ -298,3 +298,88 @@ def test_asynchrony_term_by_itself_at_config2_shape(c2_shape_jobs):
              100 * (mean["engine"] - mean["ordered oracle"])))
     assert 0.003 <= mean["ordered oracle"] - mean["shuffled oracle"] <= 0.020, mean
     assert mean["ordered oracle"] - mean["engine"] <= 0.025, mean
+
+
+# ---- the table trainer's quota: no hump from x 0.5 to x 2 of the default -----------------------------------------
+def _every_of(model, n_rows, epochs):
+    """the trainer's effective quota of the last fit: one staged step per this many rows"""
+    steps = model.last_fit_report["geometry"]["table_steps"]
+    return max(1, int(round(float(n_rows) * epochs / max(steps, 1))))
+
+
+def test_table_quota_sweep_on_the_reference_backed_feature_fixture():
+    """tests/golden/quality_planted_tags.npz (the REFERENCE's own fits): hit_rate@10 of the feature model within 1.0 point of the reference
+    at HALF and at TWICE the trainer's default quota as well (`tune_table_every`; four engine runs per data seed and setting).  Measured
+    (tools/feature_quality.py, profiles/r05_notes.md section 8; reference 0.4784): every 5th / 10th / 19th (default) / 40th row 0.4806 /
+    0.4795 / 0.4790 / 0.4874."""
+    from rankfm_amd import EngineOptions, RankFM, evaluation, synthetic
+    z = load_golden("quality", "planted_tags")
+    want = float(z["bpr"][:, 0].mean())
+    data = []
+    for seed in range(5):
+        d = synthetic.make_planted(seed=seed, n_users=3000, n_items=2000, mean_degree=100.0, n_tags=8)
+        data.append((pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"]),
+                     pd.DataFrame(np.column_stack([np.arange(len(d["user_tags"])), d["user_tags"]])),
+                     pd.DataFrame(np.column_stack([np.arange(len(d["item_tags"])), d["item_tags"]]))))
+    probe = RankFM(factors=20, loss="bpr", learning_rate=0.03)
+    np.random.seed(0)
+    probe.fit(data[0][0], user_features=data[0][2], item_features=data[0][3], epochs=5)
+    every = _every_of(probe, len(data[0][0]), 5)
+    got = {}
+    for name, ev in (("half", max(1, every // 2)), ("twice", every * 2)):
+        hits = []
+        for seed, (train, test, uf, itf) in enumerate(data):
+            for run in range(4):
+                m = RankFM(factors=20, loss="bpr", learning_rate=0.03, engine=EngineOptions(tune={"table_every": ev}))
+                np.random.seed(seed)
+                m.fit(train, user_features=uf, item_features=itf, epochs=5)
+                hits.append(evaluation.hit_rate(m, test, k=10))
+        got[name] = float(np.mean(hits))
+    print("feature fixture, table quota sweep: default every %d-th row; hit_rate@10 %s, reference %.4f" % (every, got, want))
+    for name, h in got.items():
+        assert abs(h - want) <= 0.010, (name, h, want)
+
+
+def test_table_quota_sweep_at_config2_shape_with_tags(c2_shape_jobs):
+    """The same sweep at config 2's shape with 8 + 8 tags (the features kernels on a full chip) against the sequential oracle: three data
+    seeds x two engine seeds per setting.  Since round 5 the trainer stops by itself once 80 % of a launch's segments are handed out
+    (kTableQuietFrom), so a quota denser than its pace no longer costs the rows their quiet period -- round 4 measured -3.8 points at
+    every 250th row.  A tags model's hit rate moves by +-0.5 point with the engine's seed (profiles/r04_notes.md section 11), so with six
+    runs per setting: the default is held to 1.0 point (measured -0.77 ... -0.17 over three sweeps; the four-seed test above is the
+    bar proper), HALF the default's spacing to 1.5 (measured -0.29, -0.34, -1.04), TWICE the spacing -- which trains the tables too little
+    and is the open end of SURVEY section 8 row a6 -- to 2.0 (measured -1.4, -1.4)."""
+    from rankfm_amd import EngineOptions, RankFM, evaluation
+    data, pending = c2_shape_jobs
+    loss, F, ms = C2_VARIANTS["bpr_k32_tags"]
+    frames, oracle_hits = {}, []
+    for seed in range(C2_TAG_SEEDS):
+        d = data[seed]
+        train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
+        us, its = np.unique(d["train"][:, 0]), np.unique(d["train"][:, 1])
+        uf = pd.concat([pd.DataFrame({"u": us}), pd.DataFrame(d["user_tags"][us])], axis=1)
+        itf = pd.concat([pd.DataFrame({"i": its}), pd.DataFrame(d["item_tags"][its])], axis=1)
+        frames[seed] = (train, test, uf, itf)
+        o = RankFM(factors=F, loss=loss, max_samples=ms, learning_rate=C2_TAG_LR, engine=EngineOptions(seed=100 + seed))
+        np.random.seed(seed)
+        o._init_all(train, uf, itf)
+        for k, v in pending[("bpr_k32_tags", seed)].get(timeout=1500)["weights"].items():
+            setattr(o, k, np.ascontiguousarray(v))
+        o.is_fit = True
+        oracle_hits.append(evaluation.hit_rate(o, test, k=10))
+    want = float(np.mean(oracle_hits))
+    every, got = None, {}
+    for name in ("default", "half", "twice"):
+        hits = []
+        for seed, (train, test, uf, itf) in frames.items():
+            for engine_seed in (100 + seed, 1100 + seed):
+                tune = {} if name == "default" else {"table_every": max(1, every // 2) if name == "half" else every * 2}
+                m = RankFM(factors=F, loss=loss, max_samples=ms, learning_rate=C2_TAG_LR, engine=EngineOptions(seed=engine_seed, tune=tune))
+                np.random.seed(seed)
+                m.fit(train, uf, itf, epochs=C2_TAG_EPOCHS)
+                hits.append(evaluation.hit_rate(m, test, k=10))
+                if every is None:
+                    every = _every_of(m, len(train), C2_TAG_EPOCHS)
+        got[name] = float(np.mean(hits))
+    print("config-2 shape with tags, table quota sweep: default every %d-th row; hit_rate@10 %s, oracle %.4f" % (every, got, want))
+    assert abs(got["default"] - want) <= 0.010 and abs(got["half"] - want) <= 0.015, (got, want)
+    assert abs(got["twice"] - want) <= 0.020, (got, want)
