@@ -227,7 +227,7 @@ constexpr int kMaxHot = 64;                      // hot-row accumulator slots pe
 constexpr double kHotPublications = 32.0;
 // Table trainer quota on chip-filling launches: every (kTableQuotaFactor x row groups / 64)-th row -- the 446th on a full chip.  Round 4
 // found ranking quality a HUMP in it (denser: the trainer ran to the launch's end and cost the rows their quiet period, -3.8 points of
-// hit_rate@10 at every 250th row; sparser: -1.2 at the 600th).  Since round 5 the trainer stops by itself once 80 % of the launch's
+// hit_rate@10 at every 250th row; sparser: -1.2 at the 600th).  Since round 5 the trainer stops by itself once 90 % of the launch's
 // segments are handed out (kTableQuietFrom, rfm_sgd_features.hpp) and the dense side is flat -- config-2 shape with tags, three seeds x
 // two runs against the oracle's 0.3792: every 123rd / 223rd / 246th / 300th row -0.34 / -0.29 / -0.10 / -0.29 point, 446th -0.77 ...
 // -0.17 (two runs of the sweep), 491st -0.17, 650th -1.2, 892nd -1.4 (profiles/r05_notes.md section 8).  A denser default (1.3 x, every
@@ -990,7 +990,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         a.sclk = ws.sclk;
         a.table_quota = 0;
         a.table_step = cfg->tune_table_step_pct > 0 ? (float)cfg->tune_table_step_pct * 0.01f : 1.0f;
-        a.reserved_pad = 0;
+        a.table_quiet_from = kTableQuietFrom;
         // table trainer: steps to apply in a launch of `n_units` segments beside `rowloop_wgs` row-loop workgroups.  A row-loop workgroup
         // walks about as many rows per second as the trainer applies steps (profiles/r03_notes.md section 7), so a trainer that works
         // flat out for the length of the launch gets through rows / workgroups of them; measured on config 4's share with the split
@@ -999,7 +999,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // 1.8 x: every 22nd -- or the caller's `tune_table_every`.  The rows of a launch's last part, which train against tables that have
         // STOPPED moving, are what brings the engine's tables (64 staged steps scored on one table state) to the reference's ranking
         // quality (profiles/r04_notes.md section 11); the quota's margin secures that quiet period, and since round 5 the trainer also
-        // stops by itself at 80 % of the launch's segments (kTableQuietFrom), so that a denser quota (`tune_table_every`) can no longer
+        // stops by itself at 90 % of the launch's segments (kTableQuietFrom), so that a denser quota (`tune_table_every`) can no longer
         // run to the launch's end and beyond.  Launches that do
         // not fill a good part of the chip (fewer than 4096 row groups) keep 1.8: their row loops are latency-bound and slow per row, the
         // trainer is nowhere near their length, and the 3000 x 2000 feature fixture sits within 0.3 point of the REFERENCE there (2.4
@@ -1068,7 +1068,9 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * head_rowloops ? 1 : 0;
             a.tickets = tickets_of((int)a.launch_index);
             a.table_quota = quota_of(a.pos_end - a.pos_begin, head_rowloops, 1.8);
+            a.table_quiet_from = 0.0f;           // (the opening launch's trainer is the slower side by design: no stop of its own)
             launch(a, 1 + n_producers + head_rowloops, stream);
+            a.table_quiet_from = kTableQuietFrom;
             a.hot_direct = saved_direct;
         }
         for (int64_t p0 = u_begin + head_units; p0 < u_end; p0 += units_per_launch, ++window) {

@@ -342,7 +342,7 @@ def test_table_quota_sweep_on_the_reference_backed_feature_fixture():
 
 def test_table_quota_sweep_at_config2_shape_with_tags(c2_shape_jobs):
     """The same sweep at config 2's shape with 8 + 8 tags (the features kernels on a full chip) against the sequential oracle: three data
-    seeds x two engine seeds per setting.  Since round 5 the trainer stops by itself once 80 % of a launch's segments are handed out
+    seeds x two engine seeds per setting.  Since round 5 the trainer stops by itself once 90 % of a launch's segments are handed out
     (kTableQuietFrom), so a quota denser than its pace no longer costs the rows their quiet period -- round 4 measured -3.8 points at
     every 250th row.  A tags model's hit rate moves by +-0.5 point with the engine's seed (profiles/r04_notes.md section 11), so with six
     runs per setting: the default is held to 1.0 point (measured -0.77 ... -0.17 over three sweeps; the four-seed test above is the
