@@ -345,13 +345,14 @@ def main():
         k_ms = float(np.mean(kernel_ms)) / launches                 # average duration of ONE SGD launch
         rows_per_launch = N / launches
         achieved = bytes_per_update * rows_per_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = atomic_requests = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes / fabric requests per launch, when collected
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = "%s%s" % (args.config, "_stripes" if args.negative_stripes else "")
                 traffic = tj.get(key + "_hbm_bytes_per_launch")
+                atomic_requests = tj.get(key + "_atomic_requests_per_launch")      # TCC_EA0_ATOMIC of the final tree's kernel (config 2)
             except Exception:
                 traffic = None
         # run-to-run / box-to-box: the same binary differs by 10 - 25 % between boxes of one pool (profiles/r03_notes.md), so the line
@@ -418,7 +419,11 @@ def main():
                          # what bounds the BPR kernel (profiles/r05_notes.md): the memory-side fp32 atomic path retires 20.5 G 64-byte
                          # requests/s chip-wide on uniform targets, ~16 G/s at config 2's address mix; a BPR update issues 5 (negative) +
                          # 5 x the share of positives outside the 64 LDS-accumulated rows + the hot rows' publications and sweeps
-                         "atomic_request_capacity_per_s": {"uniform": 20.5e9, "config2_mix": 16.0e9, "source": "tools/microbench/pipe_model.hip, atomic_skew.hip (round 5)"},
+                         "atomic_request_capacity_per_s": {"uniform_targets": 20.5e9, "config2_mix_row_major": 16.7e9, "config2_mix_segment_major": 18.3e9,
+                                                           "source": "tools/microbench/pipe_model.hip, atomic_skew.hip (round 5)"},
+                         # (PMC count of the profiled run / this run's kernel time: the kernel runs AT its mix's capacity)
+                         "atomic_requests_per_update": (atomic_requests / rows_per_launch) if atomic_requests else None,
+                         "atomic_requests_per_s": (atomic_requests / (k_ms * 1e-3)) if atomic_requests else None,
                          "algorithmic_bytes_per_update": bytes_per_update, "rows_per_launch": rows_per_launch},
         }
         if strong_rec is not None:

@@ -28,8 +28,10 @@ acc = collections.defaultdict(lambda: [0, 0.0])
 for f in glob.glob(sys.argv[1] + "/*/**/*counter_collection.csv", recursive=True) + glob.glob(sys.argv[1] + "/*/*counter_collection.csv"):
     seen = set()
     for r in csv.DictReader(open(f)):
-        if "sgd_" in r["Kernel_Name"]:
-            a = acc[r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+        # per SGD launch: the row-loop kernel's counters + (models with features) those of the tables kernel that runs beside it
+        if "sgd_" in r["Kernel_Name"] or "feat_tables_kernel" in r["Kernel_Name"]:
+            a = acc[r["Counter_Name"]]; a[1] += float(r["Counter_Value"])
+            if "sgd_" in r["Kernel_Name"]: a[0] += 1
 out = {k: {"launches": n, "mean_per_launch": v / max(n, 1)} for k, (n, v) in sorted(acc.items())}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps({k: v["mean_per_launch"] for k, v in out.items()}))
