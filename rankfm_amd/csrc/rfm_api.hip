@@ -227,8 +227,8 @@ constexpr int kMaxHot = 64;                      // hot-row accumulator slots pe
 constexpr double kHotPublications = 32.0;
 // Table trainer quota on chip-filling launches: every (kTableQuotaFactor x row groups / 64)-th row -- the 446th on a full chip.  Round 4
 // found ranking quality a HUMP in it (denser: the trainer ran to the launch's end and cost the rows their quiet period, -3.8 points of
-// hit_rate@10 at every 250th row; sparser: -1.2 at the 600th).  Since round 5 the trainer stops by itself once 90 % of the launch's
-// segments are handed out (kTableQuietFrom, rfm_sgd_features.hpp) and the dense side is flat -- config-2 shape with tags, three seeds x
+// hit_rate@10 at every 250th row; sparser: -1.2 at the 600th).  Since round 5 a quota denser than the default makes the trainer stop by itself once 80 % of the
+// launch's segments are handed out (kTableQuietFrom, rfm_sgd_features.hpp) and the dense side has no cliff -- config-2 shape with tags, three seeds x
 // two runs against the oracle's 0.3792: every 123rd / 223rd / 246th / 300th row -0.34 / -0.29 / -0.10 / -0.29 point, 446th -0.77 ...
 // -0.17 (two runs of the sweep), 491st -0.17, 650th -1.2, 892nd -1.4 (profiles/r05_notes.md section 8).  A denser default (1.3 x, every
 // 246th row) was measured too: flat from x 0.5 to x 2 at that shape, but on config 4's share -- 32 + 32 tags without signal, learning
@@ -295,13 +295,14 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
 }
 
 // calls that MAY run on segment-major item rows (SgdArgs::vi_split; the workspace then holds the copy): BPR without features, Hogwild,
-// full factor rows of 16-lane row groups (k = 16, 32, 48, 64, 96, 128); debug_flags bit 9 keeps the rows row-major (experiments)
+// full factor rows of 16-lane row groups (k = 16, 32, 48, 64, 96); debug_flags bit 9 keeps the rows row-major (experiments)
 static bool vi_split_eligible(const rfm_fit_config *c) {
     const ShapeEntry *sh = pick_shape(c->n_factors);
     // (Models with features stay row-major: measured on config 4's share, the pipelined feature row loop on segment-major rows runs
     //  4.12 against 3.82 - 3.85 ms -- it is bound by its 168 registers and its latency chain, not by the atomic path, and the
     //  per-segment addresses cost it two spills: profiles/r05_notes.md.  WARP reads ~23 candidate rows per update: row-major too.)
-    return sh && sh->group == 16 && c->n_factors == sh->group * sh->kpl && c->max_samples == 1 && !c->has_user_features && !c->has_item_features &&
+    // (k = 128: the segment-major instantiation needs more than the 128 registers a 16-wavefront workgroup has -- 31 spilled -- and stays row-major)
+    return sh && sh->group == 16 && sh->kpl <= 6 && c->n_factors == sh->group * sh->kpl && c->max_samples == 1 && !c->has_user_features && !c->has_item_features &&
            c->mode == RFM_MODE_HOGWILD && c->sampler == RFM_SAMPLER_UNIFORM && !(c->debug_flags & 512);
 }
 
@@ -990,7 +991,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         a.sclk = ws.sclk;
         a.table_quota = 0;
         a.table_step = cfg->tune_table_step_pct > 0 ? (float)cfg->tune_table_step_pct * 0.01f : 1.0f;
-        a.table_quiet_from = kTableQuietFrom;
+        a.table_quiet_from = 0.0f;
         // table trainer: steps to apply in a launch of `n_units` segments beside `rowloop_wgs` row-loop workgroups.  A row-loop workgroup
         // walks about as many rows per second as the trainer applies steps (profiles/r03_notes.md section 7), so a trainer that works
         // flat out for the length of the launch gets through rows / workgroups of them; measured on config 4's share with the split
@@ -999,18 +1000,22 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // 1.8 x: every 22nd -- or the caller's `tune_table_every`.  The rows of a launch's last part, which train against tables that have
         // STOPPED moving, are what brings the engine's tables (64 staged steps scored on one table state) to the reference's ranking
         // quality (profiles/r04_notes.md section 11); the quota's margin secures that quiet period, and since round 5 the trainer also
-        // stops by itself at 90 % of the launch's segments (kTableQuietFrom), so that a denser quota (`tune_table_every`) can no longer
-        // run to the launch's end and beyond.  Launches that do
+        // stops by itself once 80 % of the launch's segments are handed out when the CALLER asks for a denser quota than this
+        // (`tune_table_every`; kTableQuietFrom), which can therefore no longer run to the launch's end and beyond.  Launches that do
         // not fill a good part of the chip (fewer than 4096 row groups) keep 1.8: their row loops are latency-bound and slow per row, the
         // trainer is nowhere near their length, and the 3000 x 2000 feature fixture sits within 0.3 point of the REFERENCE there (2.4
         // ranks it a full point ABOVE the reference -- outside the bar from the other side).
-        auto quota_of = [&](int64_t n_units_launch, int rowloop_wgs, double factor) -> int64_t {
+        auto quota_of = [&](int64_t n_units_launch, int rowloop_wgs, double factor, float *quiet_from) -> int64_t {
             const double rows = (double)N * (double)n_units_launch / (double)std::max<int64_t>(1, units);
             // (in units of 64 row groups -- sixteen wavefronts -- which is what the measurement was made with)
             double rowloop_groups = (double)rowloop_wgs * (double)(waves_per_block * groups_per_wave);
             if (max_groups > 0) rowloop_groups = std::min(rowloop_groups, (double)max_groups);
             if (rowloop_groups < 4096.0) factor = std::min(factor, 1.8);
-            const double every = cfg->tune_table_every > 0 ? (double)cfg->tune_table_every : std::max(1.0, factor * rowloop_groups / 64.0);
+            const double every_default = std::max(1.0, factor * rowloop_groups / 64.0);
+            const double every = cfg->tune_table_every > 0 ? (double)cfg->tune_table_every : every_default;
+            // a caller's quota DENSER than the default gets the trainer's own stop (kTableQuietFrom); the default and anything sparser
+            // are done long before it and keep their exact, repeatable step count
+            if (quiet_from) *quiet_from = (cfg->tune_table_every > 0 && every < every_default) ? kTableQuietFrom : 0.0f;
             return (int64_t)(rows / every);
         };
         // ticket heads of launch `w` of this epoch (dynamic segment order; debug_flags bit 7 keeps the static stride)
@@ -1067,10 +1072,9 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             a.pos_end = u_begin + head_units;
             a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * head_rowloops ? 1 : 0;
             a.tickets = tickets_of((int)a.launch_index);
-            a.table_quota = quota_of(a.pos_end - a.pos_begin, head_rowloops, 1.8);
+            a.table_quota = quota_of(a.pos_end - a.pos_begin, head_rowloops, 1.8, nullptr);
             a.table_quiet_from = 0.0f;           // (the opening launch's trainer is the slower side by design: no stop of its own)
             launch(a, 1 + n_producers + head_rowloops, stream);
-            a.table_quiet_from = kTableQuietFrom;
             a.hot_direct = saved_direct;
         }
         for (int64_t p0 = u_begin + head_units; p0 < u_end; p0 += units_per_launch, ++window) {
@@ -1078,7 +1082,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
             a.tickets = tickets_of(window);
-            if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, kTableQuotaFactor);
+            if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, kTableQuotaFactor, &a.table_quiet_from);
             launch(a, grid, stream);
         }
         if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);

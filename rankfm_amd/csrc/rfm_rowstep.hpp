@@ -69,17 +69,26 @@ struct RowStep {
     lds_int *sn_sum = nullptr;
     float sn_inv_rows = 0.0f;
     int sn_rows = 0;
-    // the user's sorted item list, held across the lanes when it has at most 4 G entries (lane s: entries s, s+G, ...; -1 pads):
-    // the membership test of a draw is then four compares and a ballot instead of a memory round trip
-    int32_t ulist[4] = {-1, -1, -1, -1};
+    // the user's sorted item list, held across the lanes when it has at most UL x G entries (lane s: entries s, s+G, ...; -1 pads):
+    // the membership test of a draw is then UL compares and a ballot instead of a memory round trip
+    // (WARP's state machine tests up to four candidates per iteration and its configurations have the long lists -- config 5's users hold
+    //  100 items on average --, where the memory path is two dependent round trips PER candidate: its kernels keep up to 8 G = 128
+    //  entries.  Round 5, same box, alternating builds: config 5's share 243.3 -> 180.8 ms per epoch, config 3 9.2 -> 8.94 ms; the BPR kernel of
+    //  config 2 -- 2 % of its rows belong to users with more than 64 items, and it is bound by its atomics -- gains nothing (2.626 against 2.628
+    //  ms) and loses nothing: BPR rows of up to 64 factors keep 8 G too, for data whose users are heavier than config 2's; wider BPR rows --
+    //  whose segment-major instantiations are short of registers as it is -- keep 4 G.)
+    //  Factor rows of at most 32 dwords (k <= 32: BASELINE config 1's k = 20, where MovieLens-like users hold 100 - 200 items) have the
+    //  registers to spare for 16 G = 256 entries, BPR and WARP alike.
+    static constexpr int UL = (!FEAT && !STRIPE && !SERIAL && G == 16) ? (KPL <= 2 ? 16 : ((WARPB || KPL <= 4) ? 8 : 4)) : 4;
+    int32_t ulist[UL];
     bool ulist_ok = false;
     float user_scale = 1.0f;          // damping of this user's step (SgdArgs::user_cap), constant over a segment
     __device__ __forceinline__ void load_ulist(int64_t lo, int64_t hi) {
         user_scale = fminf(1.0f, a.user_cap / (float)(hi - lo));
-        ulist_ok = (hi - lo) <= 4 * G;
+        ulist_ok = (hi - lo) <= UL * G;
         if (ulist_ok) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < UL; ++k) {
                 const int64_t idx = lo + sub + (int64_t)G * k;
                 ulist[k] = idx < hi ? a.csr_items[idx] : -1;
             }
@@ -87,7 +96,9 @@ struct RowStep {
     }
     __device__ __forceinline__ bool member(int64_t lo, int64_t hi, int32_t item) const {
         if (ulist_ok) {
-            const bool f = (ulist[0] == item) | (ulist[1] == item) | (ulist[2] == item) | (ulist[3] == item);
+            bool f = false;
+#pragma unroll
+            for (int k = 0; k < UL; ++k) f |= (ulist[k] == item);
             if constexpr (G == 64) return __ballot(f) != 0ull;
             else return group_ballot<G>(f) != 0u;
         }

@@ -122,12 +122,11 @@ __device__ __forceinline__ void project_dense(float xr0, float xr1, int n, const
 
 // The roles of the features kernel other than the pipelined row loop are separate (non-inlined) functions: each gets a register
 // allocation of its own, so that the trainer's batch in flight or the generic step's feature vectors do not cost the row loop spills.
-// share of a launch's segments handed out to the row loops after which the table trainer stops whatever its quota (see the trainer)
-// (0.9 of the segments HANDED OUT is ~0.83 of the launch's time: the hand-out runs ahead of the rows by the segments in flight and a
-//  chunk per workgroup.  The default quota is done at ~0.78 of the time, ~0.85 handed out: 0.8 cut it short and made its step count
-//  depend on timing, which tests/test_gpu_configs.py caught.
-//  The opening launch of a fit -- a handful of row loops beside a trainer that is MEANT to be the slower side -- runs without the stop.)
-constexpr float kTableQuietFrom = 0.9f;
+// share of a launch's segments handed out to the row loops after which the table trainer stops (SgdArgs::table_quiet_from; see the
+// trainer).  Set by the host ONLY for a caller's quota denser than the default: the default quota is done at ~0.78 of the row loops'
+// time (~0.85 of the segments handed out -- the hand-out runs ahead of the rows by the segments in flight and a chunk per workgroup) and
+// must keep its exact, repeatable step count; the opening launch of a fit, whose trainer is the slower side by design, has no stop either.
+constexpr float kTableQuietFrom = 0.8f;
 
 template <int G, int KPL>
 __device__ __forceinline__ void feat_table_trainer(const SgdArgs &a, lds_float *lds, lds_int *s_stop_p) {
@@ -201,11 +200,11 @@ __device__ __forceinline__ void feat_table_trainer(const SgdArgs &a, lds_float *
         slot_of(q, p, par, m);
         if (threadIdx.x == 0) {
             int stop = applied >= quota ? 1 : 0;
-            // Safety net (round 5): whatever the quota, the trainer stops once the row loops have been handed kTableQuietFrom (0.9) of the
-            // launch's segments -- a quota denser than the trainer's pace used to keep it running to the launch's end and beyond
+            // Safety net (round 5, quotas denser than the default): the trainer stops once the row loops have been handed table_quiet_from of
+            // the launch's segments -- a quota denser than the trainer's pace used to keep it running to the launch's end and beyond
             // (every 223rd row on config 4's share: a 5.8 ms tables kernel beside 4.0 ms of row loops), which leaves the rows no
             // quiet period against tables that have stopped moving (profiles/r04_notes.md section 11: -3.8 points of hit_rate@10).
-            // The default quota is done at ~0.78 of the row loops' time and never meets this.  The counter of segments handed out is
+            // The counter of segments handed out is
             // only ever written by memory-side atomics: read through one (a load would be served from this XCD's L2).
             if (!stop && a.table_quiet_from > 0.0f && a.tickets != nullptr && a.pos_end > a.pos_begin) {
                 const unsigned handed = __hip_atomic_fetch_add(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
