@@ -323,8 +323,12 @@ def main():
         torch.cuda.synchronize()
         exchange_ms = float(e0.elapsed_time(e1))
         del scratch
-        if hasattr(trainer.shared, "exposed_exchange_ms"):
+        if trainer.late and hasattr(trainer.shared, "exposed_exchange_ms"):
             exposed_ms, n_exchanges = trainer.shared.exposed_exchange_ms()
+        else:
+            # blocking exchanges are exposed by construction: every one of them, for its whole length
+            n_exchanges = sum(trainer.exchanges_in_epoch(e) for e in range(args.warmup, args.warmup + args.steps))
+            exposed_ms = exchange_ms * n_exchanges
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
