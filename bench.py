@@ -156,7 +156,7 @@ def strong_scaling_record(world, rank, device, steps, warmup, barrier):
                  x_uf=sh["x_uf"], v_u=w["v_u"])
     hyper = dict(alpha=0.01, beta=0.1, learning_rate=cfg["learning_rate"], learning_schedule="constant", learning_exponent=0.25, max_samples=1)
     trainer, _ = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, sh["x_if"], hyper, device, seed=1492,
-                                     has_user_features=1, has_item_features=1, overlap=True)
+                                     has_user_features=1, has_item_features=1, overlap="auto")
     broadcast_from_rank0([trainer.shared.flat])
     epoch = 0
     for _ in range(warmup):
