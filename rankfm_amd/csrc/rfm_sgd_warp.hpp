@@ -23,10 +23,48 @@ namespace rfm {
 // FULL: the factor rows fill the lanes (F == G * KPL: 64 or 128 factors, ...): no per-dword bounds predicate anywhere -- the kernel is
 // bound by its vector instructions (PMC: the SIMDs' vector ALUs are ~80 % busy on config 3), and every predicate is a compare, an
 // exec-mask save and a branch around a load.
+//
+// DEFER (full rows, plain loads): a finished row's atomics are issued BEHIND the next iteration's gathers instead of in front of them.
+// A wavefront has ONE in-order counter for its vector-memory operations (vmcnt: gfx9 has no separate store counter), so a wait for
+// the gathered rows is also a wait for every atomic issued before them -- and the round trip of a memory-side fp32 atomic is the
+// longest there is: with the row updates left out the kernel runs 27 % faster on config 3 (profiles/r05_notes.md section 13), which is
+// what waiting for them costs.  Issued behind the gathers they have a whole iteration to retire in, and the wait for the gathers
+// becomes `s_waitcnt vmcnt(<the atomics just issued>)`.  The compiler cannot write that wait: the atomics are conditional (a group
+// has a finished row or not, its positive item is an LDS-accumulated hot row or not), and across a branch that may skip them its
+// counter model falls back to vmcnt(0).  So in this form the gathers are issued from inline assembly (the compiler does not know they
+// are loads and waits for nothing), the pending atomics follow as ordinary code on one of three wavefront-uniform paths -- none
+// pending / negative rows only / positive and negative rows -- on which the number of atomic INSTRUCTIONS issued is fixed (KPL + 1 per
+// row kind: every `if` around them has at least one lane inside, by the path's own condition), and each path ends in its own counted
+// wait, after which the gathered registers are handed to the compiler (`settle`).  Anything the compiler adds in between can only
+// make the wait longer than needed, never shorter: younger operations it does not know of are waited for as well.
+// One group alone (the sequential program) keeps the old order: the next row must read what this one wrote.
+template <int OFF>
+__device__ __forceinline__ float gather_f32(const float *p) {
+    float x;
+    asm volatile("global_load_dword %0, %1, off offset:%2" : "=v"(x) : "v"(p), "n"(OFF) : "memory");
+    return x;
+}
+template <int N>
+__device__ __forceinline__ void wait_gathers_behind() {      // at most N younger vector-memory operations still in flight
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+__device__ __forceinline__ void settle(float &x) { asm volatile("" : "+v"(x)); }
+// lane q (0 ... 3; a constant once the caller's loop is unrolled) of every 16-lane row, in all of the row's lanes: DPP row_newbcast
+__device__ __forceinline__ float row_bcast(float x, int q) {
+    switch (q) {
+    case 0: return dpp_mov<0x150>(x);
+    case 1: return dpp_mov<0x151>(x);
+    case 2: return dpp_mov<0x152>(x);
+    default: return dpp_mov<0x153>(x);
+    }
+}
+
 template <int G, int KPL, bool FRESH, bool HOT, bool FULL>
 __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArgs a) {
     static_assert(G == 16, "the WARP state machine is written for 16-lane row groups");
     constexpr int NC = KPL >= 8 ? 2 : 4;                    // item rows a group gathers per iteration
+    constexpr bool DEFER = FULL && !FRESH && KPL <= 4;      // (wider rows: the pending deltas do not fit beside two gathered rows in 128 registers)
     constexpr int kSweepEvery = 4;                          // (an iteration is a fraction of a row step: sweep the bins every 4th turn)
     const int lane = threadIdx.x & 63;
     const int sub = lane % G, lane_base = lane - sub;
@@ -35,6 +73,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
     if (a.max_groups > 0 && a.max_groups < n_groups) n_groups = a.max_groups;
     const int F = FULL ? G * KPL : a.n_factors;
     auto ok = [&](int kk) { return FULL || sub + G * kk < F; };
+    auto vi_at = [&](int32_t item, int k) { return a.v_i + (size_t)item * F + sub + G * k; };      // (row-major: see rfm_api.hip, vi_split_eligible)
     extern __shared__ __attribute__((aligned(16))) float lds_tables[];
     lds_float *lds = (lds_float *)lds_tables;
     typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, true, false> Step;       // draws, membership test, fixed-point hot sums
@@ -107,6 +146,21 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
     float vi[KPL], vj[KPL];
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vi[k] = vj[k] = 0.0f;
+    // DEFER: a finished row's deltas wait in vi / vj / wi / wj (dead until the group's next row is examined) for the next gathers
+    bool pend = false;
+    int32_t pi = -1, pj = 0;                                // (pi < 0: the positive item's delta went to the LDS sums)
+    auto issue_pending = [&](bool with_pos) {
+        if (with_pos && pend && pi >= 0) {
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) atomic_add_f32(vi_at(pi, k), vi[k]);
+            if (sub == 0) atomic_add_f32(a.w_i + (size_t)pi * a.w_stride, wi);
+        }
+        if (pend) {
+#pragma unroll
+            for (int k = 0; k < KPL; ++k) atomic_add_f32(vi_at(pj, k), vj[k]);
+            if (sub == 0) atomic_add_f32(a.w_i + (size_t)pj * a.w_stride, wj);
+        }
+    };
 
     for (int iter = 0;; ++iter) {
         if (!__any(active)) break;
@@ -142,6 +196,9 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
             have = true;
             in_row = false;
             step.load_ulist(lo, hi);
+            // (DEFER: everything the segment start loaded has arrived before the row loop goes on -- the compiler would otherwise wait
+            //  for it with vmcnt(0) at every row start, where its model merges this path in, and with it for the atomics in flight)
+            if constexpr (DEFER) __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         // ---- gather: the item rows this group looks at in this iteration (slot 0 = the positive item when a row starts) ----------
         const bool starts = active && !in_row;
@@ -171,16 +228,51 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
         float vc[NC][KPL];
         float wsc = 0.0f, ssc = 1.0f;                       // lane q of the group: bias and step scale of slot q's item
         int32_t mine = 0;                                   // ... and the item itself
+        if constexpr (DEFER) {
 #pragma unroll
-        for (int q = 0; q < NC; ++q) {
-            const int32_t cq = skip[q] ? 0 : c[q];
-            const float *row = a.v_i + (size_t)cq * F + sub;
+            for (int q = 0; q < NC; ++q) {
+                const int32_t cq = skip[q] ? 0 : c[q];
+                const float *row = vi_at(cq, 0);
+                vc[q][0] = gather_f32<0>(row);
+                if constexpr (KPL > 1) vc[q][1] = gather_f32<4 * G>(row);
+                if constexpr (KPL > 2) vc[q][2] = gather_f32<8 * G>(row);
+                if constexpr (KPL > 3) vc[q][3] = gather_f32<12 * G>(row);
+                static_assert(!DEFER || KPL <= 4, "the gathers spell out the row's dwords");
+                mine = sub == q ? cq : mine;
+            }
+            wsc = gather_f32<0>(a.w_i + (size_t)mine * a.w_stride);
+            if (a.pos_scale) ssc = gather_f32<0>(a.scale_in_pad ? a.w_i + (size_t)mine * a.w_stride + 1 : a.pos_scale + mine);
+            // the finished rows' atomics, behind the gathers; then the wait that leaves exactly them in flight
+            if (__any(pend)) {
+                if (__any(pend && pi >= 0)) {
+                    issue_pending(true);
+                    wait_gathers_behind<2 * (KPL + 1)>();
+                } else {
+                    issue_pending(false);
+                    wait_gathers_behind<KPL + 1>();
+                }
+                pend = false;
+            } else {
+                wait_gathers_behind<0>();
+            }
 #pragma unroll
-            for (int k = 0; k < KPL; ++k) vc[q][k] = ok(k) ? load_f32<FRESH>(row + G * k) : 0.0f;
-            mine = sub == q ? cq : mine;
+            for (int q = 0; q < NC; ++q) {
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) settle(vc[q][k]);
+            }
+            settle(wsc);
+            settle(ssc);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int32_t cq = skip[q] ? 0 : c[q];
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) vc[q][k] = ok(k) ? load_f32<FRESH>(vi_at(cq, k)) : 0.0f;
+                mine = sub == q ? cq : mine;
+            }
+            wsc = load_f32<FRESH>(a.w_i + (size_t)mine * a.w_stride);
+            if (a.pos_scale) ssc = a.scale_in_pad ? a.w_i[(size_t)mine * a.w_stride + 1] : a.pos_scale[mine];
         }
-        wsc = load_f32<FRESH>(a.w_i + (size_t)mine * a.w_stride);
-        if (a.pos_scale) ssc = a.scale_in_pad ? a.w_i[(size_t)mine * a.w_stride + 1] : a.pos_scale[mine];
         // ---- examine, in draw order ------------------------------------------------------------------------------------------
         float part[NC];
 #pragma unroll
@@ -191,9 +283,12 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
         }
         bool done = false;
         if (active) {
+            // (straight-line: every slot's verdict is a handful of selects -- as branches, the four slots were a dozen exec-mask
+            //  regions with the register copies that come with them; slot q's bias and step scale come from lane q of the group
+            //  through a DPP row broadcast instead of an LDS permute)
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
-                const float wq = __shfl(wsc, lane_base + q), sq = __shfl(ssc, lane_base + q);
+                const float wq = row_bcast(wsc, q), sq = row_bcast(ssc, q);
                 if (q == 0 && starts) {
                     // the positive item: its row, bias and step scale; a hot item's pending updates in this workgroup's LDS are part
                     // of the view (RowStep, HOT); :239
@@ -220,21 +315,21 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                         }
                     }
                     ut_ui = wi + group_sum<G>(pp);
-                    continue;
                 }
                 const float dot = group_sum<G>(part[q]);
-                if (done || skip[q] || s > a.max_samples) continue;
+                const bool take = !(q == 0 && starts) && !done && !skip[q] && s <= a.max_samples;
                 const float pu = ut_ui - (wq + dot);                               // :256-257
-                sampled = s;
-                ++s;
-                if (pu < min_pu || j < 0) {                                        // :259-261 (j < 0: keep a valid index under NaN)
-                    if (pu < min_pu) min_pu = pu;
-                    j = c[q]; wj = wq;
-                    neg_scale_j = sq;                                              // (raw: decoded when the row is finished)
+                const bool lower = pu < min_pu;
+                const bool better = take && (lower || j < 0);                      // :259-261 (j < 0: keep a valid index under NaN)
+                sampled = take ? s : sampled;
+                s += take ? 1 : 0;
+                min_pu = (take && lower) ? pu : min_pu;
+                j = better ? c[q] : j;
+                wj = better ? wq : wj;
+                neg_scale_j = better ? sq : neg_scale_j;                           // (raw: decoded when the row is finished)
 #pragma unroll
-                    for (int k = 0; k < KPL; ++k) vj[k] = vc[q][k];
-                }
-                if (pu < kMargin) done = true;                                     // :263-264
+                for (int k = 0; k < KPL; ++k) vj[k] = better ? vc[q][k] : vj[k];
+                done = done || (take && pu < kMargin);                             // :263-264
             }
             if (s > a.max_samples) done = true;                                    // the loop's range is exhausted (:247)
             if (attempt >= kMaxAttempts) { if (sub == 0) atomicOr(a.error_flags, 1u); done = true; }      // (a safety net: the host rejects saturated users)
@@ -250,7 +345,13 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
         if (active && done) {
             const SgdArgs c = cold_args();
             const float pu = min_pu;                                               // :267-268
-            const float multiplier = n_mult ? l_mult[sampled] : c.multiplier[sampled];   // :269 (integer division inside the log)
+            float multiplier;                                                      // :269 (integer division inside the log)
+            if (n_mult) multiplier = l_mult[sampled];
+            else if constexpr (DEFER) {        // (max_samples > 255: a load of its own, waited for inside this branch)
+                multiplier = gather_f32<0>(c.multiplier + sampled);
+                wait_gathers_behind<0>();
+                settle(multiplier);
+            } else multiplier = c.multiplier[sampled];
             float log_sig, d_outer;
             sigmoid_terms(pu, log_sig, d_outer);                                   // :270, :276
             if (sub == 0) { ll_acc += (double)log_sig; draw_acc += (unsigned)sampled; }
@@ -286,7 +387,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                             if (!ok(k)) continue;
                             const float d = step.hot_take(step.hot_acc + slot * F + sub + G * k);
                             if (d != 0.0f)
-                                atomic_add_f32(c.hot_direct ? a.v_i + (size_t)i * F + sub + G * k
+                                atomic_add_f32(c.hot_direct ? vi_at(i, k)
                                                             : c.hot_bins_v + hot_bin_v(c, blockIdx.x % kHotBins, slot, sub + G * k), d);
                         }
                         if (sub == 0) {
@@ -296,16 +397,26 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
                     }
                 }
             }
-            if (!hot_done) {
+            if (DEFER && !c.single_group) {
+                pend = true;
+                pi = hot_done ? -1 : i;
+                pj = j;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) { vi[k] = d_i[k]; vj[k] = d_j[k]; }
+                wi = dwi;
+                wj = dwj;
+            } else {
+                if (!hot_done) {
+#pragma unroll
+                    for (int k = 0; k < KPL; ++k)
+                        if (ok(k)) atomic_add_f32(vi_at(i, k), d_i[k]);
+                    if (sub == 0) atomic_add_f32(a.w_i + (size_t)i * a.w_stride, dwi);
+                }
 #pragma unroll
                 for (int k = 0; k < KPL; ++k)
-                    if (ok(k)) atomic_add_f32(a.v_i + (size_t)i * F + sub + G * k, d_i[k]);
-                if (sub == 0) atomic_add_f32(a.w_i + (size_t)i * a.w_stride, dwi);
+                    if (ok(k)) atomic_add_f32(vi_at(j, k), d_j[k]);
+                if (sub == 0) atomic_add_f32(a.w_i + (size_t)j * a.w_stride, dwj);
             }
-#pragma unroll
-            for (int k = 0; k < KPL; ++k)
-                if (ok(k)) atomic_add_f32(a.v_i + (size_t)j * F + sub + G * k, d_j[k]);
-            if (sub == 0) atomic_add_f32(a.w_i + (size_t)j * a.w_stride, dwj);
             // (one group alone is a sequential program: the next row must read what this one wrote)
             if (c.single_group) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
             if (++t == len) {
@@ -327,6 +438,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
             }
         }
     }
+    if constexpr (DEFER) issue_pending(true);        // (the last finished rows)
     if constexpr (HOT) {          // publish whatever is still pending
         __syncthreads();
         for (int k = threadIdx.x; k < a.n_hot * F; k += blockDim.x) {
