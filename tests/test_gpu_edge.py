@@ -46,6 +46,22 @@ def test_tiny_problems(oracle, F):
                 np.testing.assert_allclose(g[k], o[k], err_msg="%s F=%d flags=%d" % (k, F, flags), **tol)
 
 
+def test_independent_rows_in_hogwild_equal_the_sequential_program(oracle):
+    """Rows that share neither a user nor an item, negatives drawn from a catalogue large enough that no drawn item is another row's:
+    the order of execution cannot matter, so plain Hogwild must land on the sequential oracle's weights at the single-group tolerance.
+    This pins the WARP kernel's deferred row updates (rfm_sgd_warp.hpp, DEFER: a finished row's atomics are issued behind the group's NEXT
+    gathers, the last ones behind the loop) -- an update issued late, twice or never shows here -- and the BPR kernel's likewise."""
+    U, I, F = 64, 200_000, 64
+    pairs = np.array([[u, 1000 + 997 * u] for u in range(U - 1)] + [[U - 1, I - 1]], np.int32)      # (the last item id sets the catalogue's size)
+    csr = _csr(pairs, U)
+    sw = np.ones(U, np.float32)
+    for max_samples in (10, 1):
+        g, rep, o, out = _run(pairs, csr, sw, F, max_samples, 2, 21, dict(debug_flags=0), oracle)
+        for k in WEIGHTS:
+            np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg="%s max_samples=%d" % (k, max_samples))
+        assert len(rep["log_likelihood"]) == 2
+
+
 def test_duplicate_interactions_and_zero_weights(oracle):
     """the reference keeps repeated (user, item) rows -- each is a step (rankfm/rankfm.py:174 sorts, does not dedupe) -- and a
     zero sample weight leaves only the L2 shrink"""
