@@ -235,7 +235,9 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *dev, void *
 int rfm_fit_host(const rfm_fit_config *cfg, const rfm_fit_buffers *host, int device, rfm_fit_report *report);
 
 /* rfm_fit_host keeps its device staging allocation between calls (one per device, grown on demand; an allocation above 1 GiB is
- * freed when its call returns); this releases them all.  The Python binding calls it at interpreter exit. */
+ * freed when its call returns), and so do rfm_predict_host / rfm_recommend_host (one serving allocation per device for the model,
+ * the inputs and the workspace; calls on one device are serialised); this releases them all.  The Python binding calls it at
+ * interpreter exit. */
 void rfm_release_cache(void);
 
 /* ---- `_predict` (rankfm/_rankfm.pyx:345-390): pairs are float32 [n,2] indexes, NaN = unknown id ---- */

@@ -1208,7 +1208,10 @@ static std::mutex &fit_mutex(int device) {
 // the life of the process and starve later torch / predict allocations).
 constexpr size_t kArenaKeepBytes = (size_t)1 << 30;
 
+__attribute__((visibility("hidden"))) void rfm_serve_release_cache(void);      // rfm_infer.hip: the serving arenas of rfm_predict_host / rfm_recommend_host
+
 void rfm_release_cache(void) {
+    rfm_serve_release_cache();
     int n = 0, cur = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return;
     (void)hipGetDevice(&cur);

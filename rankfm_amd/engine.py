@@ -148,3 +148,54 @@ class DeviceSession:
 
     def weights_to_host(self):
         return {k: v.detach().cpu().numpy() for k, v in self.weights.items()}
+
+    # ---- serving on the resident model: `_predict` / `_recommend` (rankfm/_rankfm.pyx:345-390, 393-460) without the uploads of the
+    #      host entry points -- the model, the feature matrices and the users' item lists are already in HBM --------------------------------
+    def _model_view(self):
+        w = self.weights
+        return _hip.ModelView(
+            n_users=self.n_users, n_items=self.n_items, n_user_features=self.n_user_features, n_item_features=self.n_item_features,
+            n_factors=self.n_factors, has_user_features=self.has_uf, has_item_features=self.has_if,
+            x_uf=self.x_uf.data_ptr(), x_if=self.x_if.data_ptr(), w_i=w["w_i"].data_ptr(), w_if=w["w_if"].data_ptr(),
+            v_u=w["v_u"].data_ptr(), v_i=w["v_i"].data_ptr(), v_uf=w["v_uf"].data_ptr(), v_if=w["v_if"].data_ptr())
+
+    def _to_device(self, a, ndim, what):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if t.dim() != ndim:
+            raise ValueError("[%s] must have %d dimension(s)" % (what, ndim))
+        return t
+
+    def predict(self, pairs, to_host=True):
+        """float32 [n, 2] (user, item) index pairs (NaN = unknown id) -> float32 [n] scores, NaN where either index is NaN"""
+        pairs_d = self._to_device(pairs, 2, "pairs")
+        scores = torch.empty(pairs_d.shape[0], dtype=torch.float32, device=self.device)
+        mv = self._model_view()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = _hip.lib().rfm_predict_device(C.byref(mv), pairs_d.shape[0], C.c_void_p(pairs_d.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                               C.c_void_p(stream))
+        _hip.raise_for_status(rc)
+        return scores.cpu().numpy() if to_host else scores
+
+    def recommend(self, users, n_items=10, filter_previous=False, to_host=True):
+        """float32 [n] user indexes (NaN = unknown) -> float32 [n, n_items] item indexes by descending utility (NaN rows for unknown
+        users); `filter_previous` skips the items of the session's own CSR lists"""
+        users_d = self._to_device(users, 1, "users")
+        n_items = int(n_items)
+        if n_items < 1 or n_items > self.n_items:
+            raise ValueError("[n_items] must be between 1 and the number of training items")
+        n = int(users_d.shape[0])
+        rec = torch.empty((n, n_items), dtype=torch.float32, device=self.device)
+        mv = self._model_view()
+        need = int(_hip.lib().rfm_recommend_workspace_bytes(C.byref(mv), n, n_items))
+        ws = getattr(self, "_serve_workspace", None)
+        if ws is None or ws.numel() < need:
+            ws = self._serve_workspace = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            rc = _hip.lib().rfm_recommend_device(C.byref(mv), n, C.c_void_p(users_d.data_ptr()), C.c_void_p(self.csr_offsets.data_ptr()),
+                                                 C.c_void_p(self.csr_items.data_ptr()), n_items, int(bool(filter_previous)),
+                                                 C.c_void_p(rec.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream))
+        _hip.raise_for_status(rc)
+        return rec.cpu().numpy() if to_host else rec

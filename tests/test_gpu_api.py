@@ -275,3 +275,41 @@ def test_predict_and_recommend_match_oracle_at_scale(oracle):
             assert np.isnan(rec[5]).all() and np.isnan(ro[5]).all()
             same = rec[~np.isnan(users)] == ro[~np.isnan(users)]
             assert same.mean() > 0.995      # identical up to fp32 near-ties in the ranking
+
+
+def test_resident_session_serves_like_the_host_entry_points():
+    """`DeviceSession.predict / recommend` (rfm_predict_device / rfm_recommend_device on the session's resident model, feature matrices
+    and item lists: no uploads) return what `_predict` / `_recommend` (the host entry points, staged through the per-device serving
+    arena) return on the same weights -- also when the host entry points are called again and again (the arena is reused and regrown)."""
+    from rankfm_amd import synthetic
+    from rankfm_amd._rankfm import _predict, _recommend
+    from rankfm_amd.engine import DeviceSession
+    U, I, F, P, Q = 1500, 900, 24, 5, 6
+    rng = np.random.default_rng(3)
+    pairs, csr = synthetic.make_interactions(U, I, 40000, seed=1)
+    w = synthetic.init_weights(U, I, F, P, Q, sigma=0.5, seed=2)
+    w["w_i"] = rng.normal(0, 0.3, I).astype(np.float32)
+    w["w_if"] = rng.normal(0, 0.3, Q).astype(np.float32)
+    x_uf, x_if = synthetic.make_features(U, P, 4), synthetic.make_features(I, Q, 5)
+    args = (x_uf, x_if, w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"])
+    s = DeviceSession(pairs, np.ones(len(pairs), np.float32), csr.offsets, csr.items, x_uf, x_if, w)
+    idx = np.stack([rng.integers(0, U, 5000), rng.integers(0, I, 5000)], 1).astype(np.float32)
+    idx[::97, 0] = np.nan
+    idx[::89, 1] = np.nan
+    host = _predict(idx, *args)
+    np.testing.assert_array_equal(s.predict(idx), host)
+    users = rng.integers(0, U, 300).astype(np.float32)
+    users[5] = np.nan
+    for flt in (False, True):
+        for n_rec in (10, 25):
+            host = _recommend(users, csr, n_rec, flt, *args)
+            np.testing.assert_array_equal(s.recommend(users, n_rec, flt), host)
+            np.testing.assert_array_equal(_recommend(users[:7], csr, n_rec, flt, *args), host[:7])      # (a smaller call on the kept arena)
+    assert np.isnan(s.recommend(users, 10, True)[5]).all()
+    with pytest.raises(ValueError):
+        s.recommend(users, 0)
+    # ... and after training a little, the session serves the weights it trained
+    s.run(epochs=1)
+    trained = s.weights_to_host()
+    args2 = (x_uf, x_if, trained["w_i"], trained["w_if"], trained["v_u"], trained["v_i"], trained["v_uf"], trained["v_if"])
+    np.testing.assert_array_equal(s.recommend(users, 10, True), _recommend(users, csr, 10, True, *args2))

@@ -17,3 +17,17 @@ for rep in range(2):
     r = _recommend(users, csr, 10, True, *args); t2 = time.perf_counter()
     print("predict %d pairs: %.1f ms   recommend %d users x %d items top-10 (filter_previous): %.1f ms  [host buffers, upload included]" % (
         len(idx), (t1 - t0) * 1e3, len(users), I, (t2 - t1) * 1e3), flush=True)
+
+# the same calls on a resident session (model, features and item lists already in HBM: rfm_predict_device / rfm_recommend_device)
+import torch
+from rankfm_amd.engine import DeviceSession
+sess = DeviceSession(pairs, np.ones(len(pairs), np.float32), csr.offsets, csr.items, z_u, z_i, w)
+users_d = torch.from_numpy(users).to(sess.device)
+idx_d = torch.from_numpy(idx).to(sess.device)
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); s2 = sess.predict(idx_d, to_host=False); torch.cuda.synchronize(); t1 = time.perf_counter()
+    r2 = sess.recommend(users_d, 10, True, to_host=False); torch.cuda.synchronize(); t2 = time.perf_counter()
+    r3 = sess.recommend(users, 10, True); t3 = time.perf_counter()
+    print("resident session: predict %.2f ms   recommend %.2f ms (device in, device out)   %.2f ms (host user ids in, host lists out)" % (
+        (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3), flush=True)
+assert np.array_equal(r3, r, equal_nan=True)
