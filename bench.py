@@ -88,7 +88,7 @@ def kernel_name(F, max_samples, n_uf, n_if):
     if max_samples > 1:
         return "rfm::sgd_warp_kernel<16, %d, false, true, %s>" % (kpl, "true" if F == 16 * kpl else "false")
     # (BPR with hot-row accumulators; full factor rows run on segment-major item rows: the last template argument)
-    return "rfm::sgd_segments_kernel<16, %d, false, true, false, false, %s>" % (kpl, "true" if F == 16 * kpl else "false")
+    return "rfm::sgd_segments_kernel<16, %d, false, true, false, %s>" % (kpl, "true" if F == 16 * kpl else "false")
 
 
 def also_workload(name, device, c2_shard, c2_x_if, c2_weights, steps=5, warmup=2):
@@ -114,7 +114,7 @@ def also_workload(name, device, c2_shard, c2_x_if, c2_weights, steps=5, warmup=2
     gen_s = time.perf_counter() - t0
     N = len(data[0])
     sess = DeviceSession(*data, {k: np.array(v, copy=True) for k, v in weights.items()}, seed=1492, device=device,
-                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
+                         has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0), keep_layout=True,
                          learning_rate=cfg.get("learning_rate", 0.1), max_samples=cfg["max_samples"])
     sess.run(epochs=warmup)
     torch.cuda.synchronize()
@@ -133,7 +133,8 @@ def also_workload(name, device, c2_shard, c2_x_if, c2_weights, steps=5, warmup=2
            "kernel": kernel_name(F, cfg["max_samples"], n_uf, n_if), "rows": N, "steps": steps, "warmup": warmup,
            "kernel_ms_min": float(k.min()), "kernel_ms_median": float(np.median(k)), "sgd_launches_per_epoch": launches,
            "mean_draws": draws, "algorithmic_bytes_per_update": bpu,
-           "frac": bpu * (N / launches) / (float(np.median(k)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+           "frac": bpu * (N / launches) / (float(np.median(k)) * 1e-3) / 1e9 / HBM_PEAK_GBPS,       # (the SGD launch alone, median)
+           "frac_of_step": N * steps / elapsed * bpu / 1e9 / HBM_PEAK_GBPS,                            # (from updates/s on the wall clock)
            "updates_per_s": N * steps / elapsed, "sampled_negatives_per_s": float(np.sum(rep["n_draws"])) / elapsed,
            "data_generation_s": gen_s}
     del sess
@@ -207,10 +208,11 @@ def main():
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
     ap.add_argument("--weak", action="store_true", help="configs 4 / 5: weak scaling (every rank its own config-sized shard)")
     ap.add_argument("--learning-rate", type=float, default=0.0, help="override the config's learning rate")
-    ap.add_argument("--negative-stripes", action="store_true", help="time the opt-in stripe sampler (a library built with RFM_STRIPES=1 only) instead of the reference's uniform one")
     ap.add_argument("--also", default="C3,C4,C5", help="N = 1, config 2: the other configurations appended to the line as `also` (empty = none)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling sub-record (config 4 sharded over the ranks)")
-    ap.add_argument("--tune", default="", help="geometry overrides of rfm_fit_config (experiments): 'stripe_window=12,segment_rows=32'")
+    ap.add_argument("--tune", default="", help="geometry overrides (rfm_fit_tuning, experiments): 'hot_publications=24,segment_rows=32'")
+    ap.add_argument("--per-epoch-calls", action="store_true", help="N = 1: one engine call per epoch through the multi-GPU trainer's path (what N > 1 runs between "
+                    "exchanges) instead of ONE resident call for all timed epochs")
     args = ap.parse_args()
 
     import torch
@@ -275,39 +277,63 @@ def main():
         n_local, u_local, n_job = N, U, N * world
     hyper = dict(alpha=0.01, beta=0.1, learning_rate=lr, learning_schedule="constant", learning_exponent=0.25,
                  max_samples=cfg["max_samples"])
-    trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
-                                        syncs_per_epoch=(args.syncs_per_epoch if args.syncs_per_epoch == "auto" else int(args.syncs_per_epoch)), seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
-                                        has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
-                                        shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check,
-                                        tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv},
-                                        negative_stripes=args.negative_stripes,
-                                        overlap=False if world == 1 else {"auto": "auto", "late": True, "blocking": False}[args.exchange])
-    broadcast_from_rank0([trainer.shared.flat])
+    session_kw = dict(seed=1492, n_workgroups=args.workgroups, rows_per_launch=args.rows_per_launch,
+                      has_user_features=int(n_uf > 0), has_item_features=int(n_if > 0),
+                      shape_override=args.shape, hogwild_damping=args.damping, debug_flags=args.debug_flags, check_finite=not args.no_check,
+                      tune={kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv})
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    epoch = 0
-    for _ in range(args.warmup):
-        trainer.run_epoch(epoch)
-        epoch += 1
     kernel_ms, shader_mhz, draws = [], [], 0
-    if world > 1 and hasattr(trainer.shared, "exposed_exchange_ms"):
-        trainer.shared.exposed_exchange_ms()          # (forget the warm-up's waits)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rep = trainer.run_epoch(epoch)
-        kernel_ms.append(float(rep["sgd_kernel_ms"][0]))
-        if sess is not None and sess.geometry():
-            shader_mhz.append(float(sess.geometry().get("shader_mhz", 0.0)))
-        draws += int(rep["n_draws"][0])
-        epoch += 1
-    trainer.finish()                  # (late merge: the final blocking exchange belongs to the timed region)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    resident = world == 1 and not args.per_epoch_calls
+    if resident:
+        # ONE GPU: the resident training loop.  The session keeps the model, the interactions and -- between calls -- the engine's working
+        # layout of the item-side weights in HBM (DeviceSession(keep_layout=True)); the K timed epochs are ONE call of the C ABI
+        # (rfm_fit_device, epochs = K): per epoch one SGD launch and one epoch-tail launch (finiteness of all six arrays, pending hot-row
+        # sums folded in), one report read back at the call's end.  Nothing of the reference's epoch is left out.
+        from rankfm_amd.engine import DeviceSession
+        trainer = None
+        weights = {k: w[k] for k in SHARED_NAMES}
+        weights["v_u"] = shard["v_u"]
+        sess = DeviceSession(shard["interactions"], shard["sample_weight"], shard["csr_offsets"], shard["csr_items"], shard["x_uf"], x_if,
+                             weights, device=device, keep_layout=True, **hyper, **session_kw)
+        if args.warmup > 0:
+            sess.run(epochs=args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        rep = sess.run(epochs=args.steps, epoch_begin=args.warmup)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = [float(x) for x in rep["sgd_kernel_ms"]]
+        shader_mhz = [float(sess.geometry().get("shader_mhz", 0.0))]
+        draws = int(np.sum(rep["n_draws"]))
+        rep = dict(rep, log_likelihood=rep["log_likelihood"][-1:], n_draws=rep["n_draws"][-1:])
+    else:
+        trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
+                                            syncs_per_epoch=(args.syncs_per_epoch if args.syncs_per_epoch == "auto" else int(args.syncs_per_epoch)),
+                                            overlap=False if world == 1 else {"auto": "auto", "late": True, "blocking": False}[args.exchange], **session_kw)
+        broadcast_from_rank0([trainer.shared.flat])
+        epoch = 0
+        for _ in range(args.warmup):
+            trainer.run_epoch(epoch)
+            epoch += 1
+        if world > 1 and hasattr(trainer.shared, "exposed_exchange_ms"):
+            trainer.shared.exposed_exchange_ms()          # (forget the warm-up's waits)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rep = trainer.run_epoch(epoch)
+            kernel_ms.append(float(rep["sgd_kernel_ms"][0]))
+            if sess is not None and sess.geometry():
+                shader_mhz.append(float(sess.geometry().get("shader_mhz", 0.0)))
+            draws += int(rep["n_draws"][0])
+            epoch += 1
+        trainer.finish()                  # (late merge: the final blocking exchange belongs to the timed region)
+        barrier()
+        elapsed = time.perf_counter() - t0
     # N > 1: what an exchange costs by itself (one blocking all-reduce of a bucket-sized buffer, HIP events) and how much of the
     # exchanges the rank's stream actually waited for (SharedTables.exposed_exchange_ms: ~0 when the late merge hides them)
     exchange_ms = exposed_ms = None
@@ -348,13 +374,17 @@ def main():
         bytes_per_update = algorithmic_bytes_per_update(F, n_uf, n_if, mean_draws)
         k_ms = float(np.mean(kernel_ms)) / launches                 # average duration of ONE SGD launch
         rows_per_launch = N / launches
-        achieved = bytes_per_update * rows_per_launch / (k_ms * 1e-3) / 1e9
+        # achieved = updates/s x algorithmic bytes per update -- from `value` (the whole step: SGD launch, epoch
+        # tail, host), per GPU; the SGD launch by itself (HIP events around it, what rocprofv3's per-kernel average is compared with)
+        # is reported beside it as `kernel_only`
+        achieved = value / world * bytes_per_update / 1e9
+        achieved_kernel = bytes_per_update * rows_per_launch / (k_ms * 1e-3) / 1e9
         traffic = atomic_requests = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes / fabric requests per launch, when collected
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "%s%s" % (args.config, "_stripes" if args.negative_stripes else "")
+                key = args.config
                 traffic = tj.get(key + "_hbm_bytes_per_launch")
                 atomic_requests = tj.get(key + "_atomic_requests_per_launch")      # TCC_EA0_ATOMIC of the final tree's kernel (config 2)
             except Exception:
@@ -368,15 +398,10 @@ def main():
                     "interactions, all items)" % (args.config, 0 if world == 1 else rank, world if world > 1 else max(args.share, 1), U, I, cfg["n_interactions"], u_local, n_local))
         else:
             what = "%s: synthetic %d users x %d items x %d interactions per GPU" % (args.config, U, I, N)
-        # which sampler the timed kernel used: the reference draws every negative uniformly over the catalogue
-        # (rankfm/_rankfm.pyx:250-253); large BPR launches draw a window's negatives from a stripe of items held in LDS
         geo = sess.geometry() if sess is not None else {}
-        if geo.get("stripe_rows", 0) > 0:
-            sampler = ("negative stripes: each workgroup draws the negatives of a window of %d rows per row group from %d items held in LDS "
-                       "(stripes tile a keyed permutation of the catalogue, every item offered equally often), user segments <= %d rows"
-                       % (geo["stripe_window"], geo["stripe_rows"], geo.get("segment_rows", 32)))
-        else:
-            sampler = "negatives drawn uniformly over the whole catalogue (the reference's sampler, rankfm/_rankfm.pyx:250-253), user segments <= %d rows" % (geo.get("segment_rows") or 32)
+        sampler = "negatives drawn uniformly over the whole catalogue (the reference's sampler, rankfm/_rankfm.pyx:250-253), user segments <= %d rows" % (geo.get("segment_rows") or 32)
+        calls = ("ONE resident rfm_fit_device call for the %d timed epochs (per epoch: SGD launch + epoch tail), item-side weights kept in the engine's "
+                 "layout between calls" % args.steps) if resident else "one rfm_fit_device call per epoch / exchange window (layouts converted per call)"
         peak_measured = None
         if world == 1:
             import ctypes as C
@@ -393,8 +418,8 @@ def main():
             "config": {"workload": "%s, factors=%d, loss=%s%s%s, learning_rate=%g, zipf_s=%g, hogwild fp32 atomics, counter RNG, %s"
                                    % (what, F, cfg["loss"], " max_samples=%d" % cfg["max_samples"] if cfg["max_samples"] > 1 else "",
                                       ", %d + %d dense user/item features" % (n_uf, n_if) if n_uf or n_if else "", lr, args.zipf, sampler),
-                       "sampler": {"stripe_rows": geo.get("stripe_rows", 0), "stripe_window": geo.get("stripe_window", 0),
-                                   "segment_rows": geo.get("segment_rows", 0), "workgroups": geo.get("workgroups", 0)},
+                       "calls": calls,
+                       "geometry": {"segment_rows": geo.get("segment_rows", 0), "workgroups": geo.get("workgroups", 0)},
                        "n_users_total": u_local * world, "n_interactions_total": n_job, "parallelism": "user-shard dp%d" % world,
                        "rccl_ranks_seen": (dist.get_world_size() if world > 1 and dist.get_backend() == "nccl" else (1 if world == 1 else 0)),
                        "collective_backend": dist.get_backend() if world > 1 else None,
@@ -413,6 +438,10 @@ def main():
                        "final_mean_ll_per_update": ll_last / N},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "how": "achieved = value / n_gpus x algorithmic_bytes_per_update (SURVEY.md 8d: the whole step on the wall clock); kernel_only = the "
+                                "SGD launch alone, algorithmic bytes of a launch / its HIP-event duration (compare with rocprofv3's average for `kernel`)",
+                         "kernel_only": {"achieved": achieved_kernel, "frac": achieved_kernel / HBM_PEAK_GBPS, "ms_per_launch": k_ms,
+                                         "step_minus_kernel_ms": elapsed / args.steps * 1e3 - k_ms * launches},
                          "peak_measured": peak_measured,
                          "kernel": kernel_name(F, cfg["max_samples"], n_uf, n_if),
                          "kernel_ms_per_launch": k_ms,
@@ -432,7 +461,7 @@ def main():
         }
         if strong_rec is not None:
             out["strong_scaling"] = strong_rec
-        if world == 1 and args.config == "C2" and not strong and args.also and not args.negative_stripes:
+        if world == 1 and args.config == "C2" and not strong and args.also:
             out["also"] = [also_workload(name, device, shard, x_if, w) for name in args.also.split(",") if name]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(shard, x_if, w, hyper, int(n_uf > 0), int(n_if > 0))

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RFM_ABI_VERSION 5
+#define RFM_ABI_VERSION 6
 
 typedef enum rfm_status {
     RFM_OK = 0,
@@ -63,17 +63,43 @@ typedef enum rfm_status {
 #define RFM_MODE_SERIAL 1   /* one wavefront walks the shuffled rows in order with plain read-modify-write:
                                the reference's sequential semantics (parity / debugging mode) */
 
-/* negative sampler */
-#define RFM_SAMPLER_UNIFORM 0   /* the reference's: every draw uniform over the whole catalogue (rankfm/_rankfm.pyx:250-253).  Default. */
-#define RFM_SAMPLER_STRIPES 1   /* opt-in, BPR Hogwild launches that fill the chip: a workgroup draws the negatives of a window of rows
-                                   from a stripe of items it holds in LDS and publishes their updates once per window.
-                                   ~1.5x the update rate, but NOT the reference's sampler: measured cost 1.0 point of hit_rate@10 at
-                                   30 k x 12 k and 2.3 points at 100 k x 50 k planted problems (profiles/r03_notes.md). */
-
-/* negative-draw stream */
+/* negative-draw stream.  The SAMPLER is always the reference's: every draw uniform over the whole catalogue, the user's own items
+ * drawn again (rankfm/_rankfm.pyx:250-253). */
 #define RFM_RNG_MT19937 0   /* reference stream: MT19937, `% I` (serial mode only; needs explicit perms) */
 #define RFM_RNG_COUNTER 1   /* counter-based draws keyed by (seed, epoch, row, attempt): include/rfm_rng.h */
 
+/* Experiments and tests steer the engine through THIS struct and nothing else (the library reads no environment variable); a
+ * binding that replaces the reference's `_fit` passes rfm_fit_config.tuning = NULL and never needs it.  0 = automatic everywhere. */
+typedef struct rfm_fit_tuning {
+    int32_t n_workgroups;          /* Hogwild grid size (lifts the concurrency caps); ignored in serial mode */
+    int32_t rows_per_launch;       /* > 0 splits an epoch into several launches */
+    int32_t debug_shape;           /* 1-based index into the row-group shape table */
+    int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
+                                      bit 1: factor-row loads bypass the per-CU L1,
+                                      bit 2: no LDS accumulation of hot item rows,
+                                      bit 5: models with features: the dense feature tables are NOT trained (no table trainer); with
+                                             bit 0 the row loop of the features kernel runs on one row group -- parity tests,
+                                      bit 6: models with features: no table-friendly opening launch in the fit's first epoch,
+                                      bit 7: row groups stride the epoch's segment order statically instead of taking tickets,
+                                      bit 8: the item damping scales an item's step only when it is the POSITIVE item (the round-3 rule),
+                                      bit 9: chip-filling BPR launches keep the item factor rows row-major (no segment-major working copy) */
+    int32_t segment_rows;          /* longest user segment, 1..32 (auto: 32) */
+    int32_t hot_publications;      /* publications of a hot row per epoch and workgroup (auto: 32 for BPR without features, else 48) */
+    int32_t feature_waves;         /* wavefronts per workgroup of the features kernels, 2..16 (auto: 16; the pipelined row loop 12) */
+    int32_t table_producers;       /* features: step-producer workgroups feeding the table trainer, 1..16 (auto: 3 on a full chip, 2 / 1 on
+                                      small launches) */
+    int32_t table_every;           /* features: the table trainer applies rows-of-the-launch / this many staged steps per launch (auto: 2.4 x
+                                      the launch's row groups / 64 -- every 446th row on a full chip -- on launches of at least 4096 row
+                                      groups, 1.8 x on smaller ones and in the opening launch: DESIGN.md 3.3) */
+    int32_t table_step_pct;        /* features: the table trainer's step length in percent of the epoch's learning rate (auto: 100) */
+    int32_t table_batch;           /* features: staged steps per batch of a producer, a multiple of 4 up to the row groups of the tables
+                                      kernel's workgroup (auto: all of them, 64 with 16-lane row groups) -- a batch is scored on ONE state of
+                                      the tables, DESIGN.md 3.3 */
+    int32_t reserved;              /* 0 */
+} rfm_fit_tuning;
+
+/* What a binding of the reference's `_fit` fills in: its 19 arguments' scalars (rankfm/_rankfm.pyx:122-142), the engine's mode and
+ * seed, and the two tokens a resident caller hands back. */
 typedef struct rfm_fit_config {
     int64_t n_interactions;        /* N */
     int32_t n_users;               /* U */
@@ -100,49 +126,26 @@ typedef struct rfm_fit_config {
     uint32_t seed;                 /* MT seed (reference: 1492) or counter seed */
     int32_t check_finite;          /* 1: epoch-end finiteness check (reference behaviour), 0: skip */
     int32_t want_penalty;          /* 1: also return the L2 penalty per epoch (verbose printing) */
-    int32_t n_workgroups;          /* 0 = auto (hogwild); ignored in serial mode */
-    int32_t rows_per_launch;       /* 0 = one launch per epoch; >0 splits an epoch into several launches */
     float hogwild_damping;         /* M: a row touched by n in-flight updates at once is stepped with min(1, M/n) of the
                                       learning rate (n = in-flight rows x the row's share of the data).  0 = default (128),
                                       < 0 = off.  Ignored in serial mode. */
-    int32_t debug_update_mode;     /* reserved, ignored (the plain-store experiments of rounds 1-2 are gone; profiles/r02_notes.md) */
-    int32_t debug_shape;           /* experiments: 1-based index into the kernel shape table, 0 = automatic */
-    int32_t debug_flags;           /* bit 0: run the Hogwild kernel on ONE row group (sequential; parity tests),
-                                      bit 1: factor-row loads bypass the per-CU L1,
-                                      bit 2: no LDS accumulation of hot item rows,
-                                      bit 3: no negative stripes even when `sampler` asks for them,
-                                      bit 4: (unused since round 4: negative stripes are BPR only),
-                                      bit 5: models with features: the dense feature tables are NOT trained (no table trainer); with
-                                             bit 0 the row loop of the features kernel runs on one row group -- parity tests,
-                                      bit 6: models with features: no table-friendly opening launch in the fit's first epoch (experiments),
-                                      bit 7: row groups stride the epoch's segment order statically instead of taking tickets (experiments),
-                                      bit 8: the item damping scales an item's step only when it is the POSITIVE item, the round-3 rule (experiments),
-                                      bit 9: chip-filling BPR launches keep the item factor rows row-major (no segment-major working copy; experiments) */
     int32_t epoch_part_index;      /* with epoch_parts > 1: run only part k (0-based) of each epoch's visiting order -- lets a */
     int32_t epoch_parts;           /* multi-GPU caller exchange item deltas several times per epoch; 0 or 1 = whole epochs    */
+    int32_t keep_layout;           /* rfm_fit_device only.  1: the call may leave the item-side weights (v_i, w_i) in the ENGINE'S working
+                                      layout inside the workspace when it returns -- segment-major factor rows, one 64-byte line per
+                                      bias, pending hot-row sums -- instead of converting them back into the caller's arrays; the
+                                      caller's v_i / w_i are then STALE until rfm_fit_export_weights() or a later call with
+                                      keep_layout = 0 on the same workspace.  rfm_fit_report.layout_token says whether it did.  A
+                                      resident training loop (one call per epoch or per exchange window) saves two passes over the item
+                                      tables per call. */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
                                       scales) into the head of `workspace`; > 0: the value rfm_fit_report.plan_token returned
                                       by an earlier call on the SAME workspace, interactions, geometry and damping -- the
                                       plan is reused and the planning pass is skipped */
-    /* Geometry overrides of the Hogwild plan, 0 = automatic (what production uses).  They exist so that experiments and the
-     * parity tools steer the engine through THIS struct and nothing else: the library reads no environment variable, and the
-     * host mirror (rankfm_amd/order.py) sees the effective values in rfm_fit_report. */
-    int32_t tune_segment_rows;     /* longest user segment, 1..32 (auto: 32, 16 for plans that use negative stripes) */
-    int32_t tune_stripe_window;    /* rows per group between stripe changes (auto: 8 I / groups, at most 32) */
-    int32_t tune_stripe_rows;      /* items per stripe (auto: groups x window / 2, at most what LDS holds); -1 = none: the pipelined
-                                      row loop of the stripe kernel with whole-catalogue draws */
-    int32_t tune_hot_publications; /* publications of a hot row per epoch and workgroup (auto: 32 for BPR without features, else 48) */
-    int32_t tune_feature_waves;    /* wavefronts per workgroup of the features kernel, 2..16 (auto: 16) */
-    int32_t tune_table_producers;      /* features kernel: step-producer workgroups feeding the table trainer, 1..16 (auto: 3 on a
-                                      full chip, 2 / 1 on small launches) */
-    int32_t sampler;               /* RFM_SAMPLER_* (0 = the reference's uniform sampler) */
-    int32_t tune_table_every;      /* features kernel: the table trainer applies rows-of-the-launch / this many staged steps per launch
-                                      (auto: 2.4 x the launch's row groups / 64 -- every 446th row on a full chip -- on launches of at least
-                                      4096 row groups, 1.8 x on smaller ones and in the opening launch: an empirical optimum) */
-    int32_t tune_table_step_pct;   /* features kernel: the table trainer's step length in percent of the epoch's learning rate (auto: 100;
-                                      experiments -- the trainer applies batches of staged steps that were scored on one table state, and a
-                                      shorter step is the lever against the noise that adds: DESIGN.md 3.3) */
-    int32_t reserved_pad;          /* (keeps the struct's size a multiple of 8) */
+    int64_t layout_token;          /* 0: the caller's v_i / w_i arrays are current (always, unless the previous call on this workspace
+                                      returned a non-zero rfm_fit_report.layout_token: then pass that value, together with its
+                                      plan_token -- the workspace holds the current item-side weights) */
+    const struct rfm_fit_tuning *tuning;   /* NULL = production */
 } rfm_fit_config;
 
 /* All pointers of one struct live in the same memory space: device memory for the *_device entry
@@ -182,10 +185,10 @@ typedef struct rfm_fit_report {
     int64_t working_groups;        /* row groups that work (the concurrency cap can be below the grid's capacity) */
     int64_t units_per_launch;      /* user segments (or rows) per launch */
     int64_t n_units;               /* user segments (or rows) per epoch */
-    int32_t stripe_rows;           /* items per negative stripe (include/rfm_rng.h), 0 = draws over the whole catalogue */
-    int32_t stripe_window;         /* rows per group between stripe changes */
-    int32_t segment_rows;          /* longest user segment of the plan (32; 16 when negative stripes are used), 0 = rows kernel */
+    int32_t segment_rows;          /* longest user segment of the plan (32), 0 = rows kernel */
     int32_t table_producers;       /* features kernel: step-producer workgroups beside the table trainer, 0 = none */
+    int64_t layout_token;          /* non-zero: the item-side weights were LEFT in the workspace in the engine's layout (keep_layout): pass it
+                                      back as rfm_fit_config.layout_token, or call rfm_fit_export_weights() before reading v_i / w_i */
     int64_t table_steps;           /* features kernel: staged steps the table trainer applied over the call (it sees every
                                       (epochs x N / table_steps)-th row of the stream) */
     int64_t feat_diag[8];          /* features kernel, microseconds over the call: the trainer waited for a batch | ran in all |
@@ -220,6 +223,12 @@ int rfm_delta_finish(float *dev_flat, const float *dev_start, const float *dev_s
  * `bytes` of device memory -- a read-only pass and a copy (read + write), best of `iters` launches each, in GB/s.  The SGD
  * path's roofline is quoted against the 8 TB/s data-sheet peak AND against this achievable figure. */
 int rfm_hbm_probe(size_t bytes, int iters, double *read_gbps, double *copy_gbps);
+
+/* Converts item-side weights that an rfm_fit_device call with keep_layout = 1 left in `dev->workspace` back into the caller's dev->v_i /
+ * dev->w_i (the reference's row-major layout), draining the pending hot-row sums first.  `cfg`: the configuration of that call with
+ * plan_token / layout_token as its report returned them.  Enqueued on `hip_stream`, no synchronisation; idempotent; the workspace stays
+ * current (a later call may still pass the tokens).  A layout_token of 0 is a no-op. */
+int rfm_fit_export_weights(const rfm_fit_config *cfg, const rfm_fit_buffers *dev, void *hip_stream);
 
 /* `_fit` on buffers already resident in HBM.  Work is enqueued on `hip_stream` (a hipStream_t; NULL =
  * the default stream); the call returns after one stream synchronisation at the end, when the report

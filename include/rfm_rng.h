@@ -74,35 +74,4 @@ RFM_HD uint32_t rfm_perm(uint32_t pos, uint32_t n, uint32_t bits, uint32_t epoch
     return x;
 }
 
-/* ---- negative stripes (Hogwild segments kernel) -----------------------------------------------------------------------
- * A workgroup draws the negatives of one WINDOW of its rows from a STRIPE of R items whose factor rows it holds in LDS
- * (rankfm_amd/csrc/rfm_sgd.hpp): R consecutive positions -- cyclically -- of a keyed permutation of the catalogue that
- * changes every epoch.  The n-th window slot of a launch (n = window * workgroups + workgroup) starts at position
- * n * R + offset (mod I): the slots tile the cycle end to end, so over any stretch of the launch every item has been offered
- * as a negative equally often (+-1) -- the per-item negative rate of the reference's uniform `genrand_int32() % I`
- * (rankfm/_rankfm.pyx:251) is kept exactly, not just on average (a hashed slot -> stripe assignment leaves Poisson
- * fluctuations in how often each stripe is used, +-20 % per epoch at 25 uses; the sequential oracle itself then learns
- * item biases 8 % larger and ranks 1-2 points worse, profiles/r02_notes.md).  A draw is uniform over the stripe; rejection of
- * the user's own items is unchanged (:250-253).  The schedule is a pure function of the launch geometry, so the host
- * mirror (rankfm_amd/order.py) hands the sequential oracle the very same negatives. */
-
-/* A row whose draws keep landing on the user's own items inside the stripe (a user who holds most of the catalogue can hold a
- * whole stripe) leaves the stripe: from its RFM_STRIPE_ATTEMPTS-th attempt on, draws range over the whole catalogue. */
-#define RFM_STRIPE_ATTEMPTS 128u
-
-/* first position (in the epoch's item permutation) of the stripe of `workgroup` (of `n_workgroups`) in its `window`-th window
- * of launch `launch`; stripe_rows <= n_items */
-RFM_HD uint32_t rfm_stripe_start(uint32_t epoch_key, uint32_t launch, uint32_t workgroup, uint32_t n_workgroups,
-                                 uint32_t window, uint32_t stripe_rows, uint32_t n_items) {
-    const uint64_t slot = (uint64_t)window * n_workgroups + workgroup;
-    return (uint32_t)((slot * stripe_rows + rfm_mix32(epoch_key ^ (0x68E31DA4U + launch))) % n_items);
-}
-
-/* item in row `r` (0 <= r < stripe_rows) of the stripe starting at `start`; item_bits = rfm_perm_bits(n_items) */
-RFM_HD uint32_t rfm_stripe_item(uint32_t epoch_key, uint32_t start, uint32_t r, uint32_t n_items, uint32_t item_bits) {
-    uint32_t p = start + r;
-    if (p >= n_items) p -= n_items;
-    return rfm_perm(p, n_items, item_bits, epoch_key ^ 0x2545F491U);
-}
-
 #endif /* RFM_RNG_H */

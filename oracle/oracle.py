@@ -34,7 +34,6 @@ class OracleParams(C.Structure):
         ("rng_mode", C.c_int32),
         ("seed", C.c_uint32),
         ("membership", C.c_int32),
-        ("stripe_rows", C.c_int32),
         ("table_every", C.c_int32), ("table_step", C.c_float),
         ("table_head_every", C.c_int32), ("table_head_rows", C.c_int64), ("table_tail", C.c_int64), ("table_quiet_rows", C.c_int64), ("table_batch", C.c_int32),
     ]
@@ -91,7 +90,7 @@ def mt_stream(seed, n):
 def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, v_u, v_i, v_uf, v_if,
         alpha, beta, learning_rate, learning_schedule, learning_exponent, max_samples, epochs,
         perms=None, rng_mode=RNG_MT19937, seed=REFERENCE_MT_SEED, epoch_begin=0, membership="linear",
-        has_uf=None, has_if=None, want_negatives=False, row_stripe=None, stripe_rows=0, pos_step=None, user_step=None, pos_step_bias=None, neg_step=None, table_every=0, table_step=0.0,
+        has_uf=None, has_if=None, want_negatives=False, pos_step=None, user_step=None, pos_step_bias=None, neg_step=None, table_every=0, table_step=0.0,
         table_head_every=0, table_head_rows=0, table_tail=0, table_quiet_rows=0, table_batch=0):
     """Run the sequential restatement of `_fit` IN PLACE on the six weight arrays.
 
@@ -121,12 +120,9 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
         schedule=0 if learning_schedule == "constant" else 1,
         learning_exponent=learning_exponent, max_samples=max_samples,
         epochs=epochs, epoch_begin=epoch_begin, rng_mode=rng_mode, seed=seed,
-        membership=0 if membership == "linear" else 1, stripe_rows=int(stripe_rows),
+        membership=0 if membership == "linear" else 1,
         table_every=int(table_every), table_step=float(table_step),      # (analysis options, rfm_oracle.c; 0 / 0 = the reference)
         table_head_every=int(table_head_every), table_head_rows=int(table_head_rows), table_tail=int(table_tail), table_quiet_rows=int(table_quiet_rows), table_batch=int(table_batch))
-    if row_stripe is not None:
-        row_stripe = np.ascontiguousarray(row_stripe, dtype=np.int32)
-        assert row_stripe.shape == (epochs, N) and rng_mode == RNG_COUNTER and stripe_rows >= 1
     if perms is not None:
         perms = np.ascontiguousarray(perms, dtype=np.int32)
         assert perms.shape == (epochs, N)
@@ -138,7 +134,7 @@ def fit(interactions, sample_weight, csr_off, csr_items, x_uf, x_if, w_i, w_if, 
             _p(_f32(x_uf), C.c_float), _p(_f32(x_if), C.c_float),
             _p(_f32(w_i), C.c_float), _p(_f32(w_if), C.c_float), _p(_f32(v_u), C.c_float),
             _p(_f32(v_i), C.c_float), _p(_f32(v_uf), C.c_float), _p(_f32(v_if), C.c_float),
-            _p(perms, C.c_int32), _p(ll, C.c_double), _p(neg, C.c_int32), _p(nsamp, C.c_int32), _p(row_stripe, C.c_int32)]
+            _p(perms, C.c_int32), _p(ll, C.c_double), _p(neg, C.c_int32), _p(nsamp, C.c_int32)]
     ll64 = np.zeros(epochs, dtype=np.float64)
     if pos_step is not None or user_step is not None:
         pos_step = np.ascontiguousarray(pos_step, dtype=np.float32)

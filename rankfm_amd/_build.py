@@ -23,15 +23,6 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
          "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
-# The stripe sampler of round 2 (RFM_SAMPLER_STRIPES: not the reference's sampler, frozen since round 3) is NOT in the default build since
-# round 5: its kernel instantiations are a third of the build and nothing ships on it.  The library answers RFM_ERR_UNSUPPORTED to
-# sampler = RFM_SAMPLER_STRIPES and the stripe tests skip.  RFM_STRIPES=1 python -m rankfm_amd._build --force  builds it back in
-# (objects of the two kinds do not mix: --force).
-WITH_STRIPES = os.environ.get("RFM_STRIPES", "") == "1"
-if not WITH_STRIPES:
-    FLAGS = FLAGS + ["-DRFM_NO_STRIPES"]
-
-
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankfm_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK = 0
 ERR_BAD_ARG, ERR_UNKNOWN_SCHEDULE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_USER_SATURATED, ERR_WORKSPACE = (
     -1, -2, -3, -4, -5, -6, -7)
@@ -17,8 +17,16 @@ ERR_NONFINITE = 100
 SCHEDULE_CONSTANT, SCHEDULE_INVSCALING = 0, 1
 MODE_HOGWILD, MODE_SERIAL = 0, 1
 RNG_MT19937, RNG_COUNTER = 0, 1
-SAMPLER_UNIFORM, SAMPLER_STRIPES = 0, 1
 REFERENCE_MT_SEED = 1492       # rankfm/_rankfm.pyx:182
+
+
+class FitTuning(C.Structure):
+    """rfm_fit_tuning: the experiments' overrides (0 = automatic everywhere); production passes none (FitConfig.tuning = NULL)"""
+    _fields_ = [
+        ("n_workgroups", C.c_int32), ("rows_per_launch", C.c_int32), ("debug_shape", C.c_int32), ("debug_flags", C.c_int32),
+        ("segment_rows", C.c_int32), ("hot_publications", C.c_int32), ("feature_waves", C.c_int32), ("table_producers", C.c_int32),
+        ("table_every", C.c_int32), ("table_step_pct", C.c_int32), ("table_batch", C.c_int32), ("reserved", C.c_int32),
+    ]
 
 
 class FitConfig(C.Structure):
@@ -32,29 +40,32 @@ class FitConfig(C.Structure):
         ("max_samples", C.c_int32), ("epochs", C.c_int32), ("epoch_begin", C.c_int32), ("rng_epoch_offset", C.c_int32),
         ("mode", C.c_int32), ("rng", C.c_int32), ("seed", C.c_uint32),
         ("check_finite", C.c_int32), ("want_penalty", C.c_int32),
-        ("n_workgroups", C.c_int32), ("rows_per_launch", C.c_int32),
         ("hogwild_damping", C.c_float),
-        ("debug_update_mode", C.c_int32), ("debug_shape", C.c_int32), ("debug_flags", C.c_int32),
-        ("epoch_part_index", C.c_int32), ("epoch_parts", C.c_int32),
-        ("plan_token", C.c_int64),
-        ("tune_segment_rows", C.c_int32), ("tune_stripe_window", C.c_int32), ("tune_stripe_rows", C.c_int32),
-        ("tune_hot_publications", C.c_int32), ("tune_feature_waves", C.c_int32), ("tune_table_producers", C.c_int32),
-        ("sampler", C.c_int32), ("tune_table_every", C.c_int32), ("tune_table_step_pct", C.c_int32), ("reserved_pad", C.c_int32),
+        ("epoch_part_index", C.c_int32), ("epoch_parts", C.c_int32), ("keep_layout", C.c_int32),
+        ("plan_token", C.c_int64), ("layout_token", C.c_int64),
+        ("tuning", C.POINTER(FitTuning)),
     ]
 
 
-#: names of the geometry overrides of rfm_fit_config (0 = automatic); EngineOptions.tune / DeviceSession(tune=...) carry them
-TUNE_FIELDS = ("segment_rows", "stripe_window", "stripe_rows", "hot_publications", "feature_waves", "table_producers", "table_every", "table_step_pct")
+#: names of the geometry overrides of rfm_fit_tuning (0 = automatic); EngineOptions.tune / DeviceSession(tune=...) carry them
+TUNE_FIELDS = ("segment_rows", "hot_publications", "feature_waves", "table_producers", "table_every", "table_step_pct", "table_batch")
 
 
 def tune_kwargs(tune):
-    """{'stripe_window': 12, ...} -> FitConfig keyword arguments (unknown names raise)"""
+    """{'segment_rows': 16, ...} -> FitTuning keyword arguments (unknown names raise)"""
     out = {}
     for k, v in (tune or {}).items():
         if k not in TUNE_FIELDS:
             raise ValueError("unknown geometry override %r (known: %s)" % (k, ", ".join(TUNE_FIELDS)))
-        out["tune_" + k] = int(v)
+        out[k] = int(v)
     return out
+
+
+def make_tuning(tune=None, n_workgroups=0, rows_per_launch=0, debug_shape=0, debug_flags=0):
+    """a FitTuning for FitConfig.tuning, or None when everything is automatic (production: the library gets a NULL pointer)"""
+    kw = dict(tune_kwargs(tune), n_workgroups=int(n_workgroups), rows_per_launch=int(rows_per_launch), debug_shape=int(debug_shape),
+              debug_flags=int(debug_flags))
+    return FitTuning(**kw) if any(kw.values()) else None
 
 
 class FitBuffers(C.Structure):
@@ -76,8 +87,8 @@ class FitReport(C.Structure):
         ("launches_per_epoch", C.c_int32), ("waves_per_launch", C.c_int32),
         ("plan_token", C.c_int64),
         ("workgroups", C.c_int32), ("groups_per_workgroup", C.c_int32), ("working_groups", C.c_int64),
-        ("units_per_launch", C.c_int64), ("n_units", C.c_int64), ("stripe_rows", C.c_int32), ("stripe_window", C.c_int32),
-        ("segment_rows", C.c_int32), ("table_producers", C.c_int32), ("table_steps", C.c_int64), ("feat_diag", C.c_int64 * 8),
+        ("units_per_launch", C.c_int64), ("n_units", C.c_int64),
+        ("segment_rows", C.c_int32), ("table_producers", C.c_int32), ("layout_token", C.c_int64), ("table_steps", C.c_int64), ("feat_diag", C.c_int64 * 8),
         ("table_overlap_us", C.c_int64), ("table_span_us", C.c_int64 * 2), ("shader_mhz", C.c_float), ("reserved_report", C.c_int32),
     ]
 
@@ -88,7 +99,7 @@ class FitReport(C.Structure):
 
     def _geometry(self):
         return {k: int(getattr(self, k)) for k in ("workgroups", "groups_per_workgroup", "working_groups", "units_per_launch",
-                                                   "n_units", "stripe_rows", "stripe_window", "launches_per_epoch", "segment_rows",
+                                                   "n_units", "launches_per_epoch", "segment_rows",
                                                    "table_producers", "table_steps")}
 
 
@@ -105,7 +116,7 @@ class ModelView(C.Structure):
 # every symbol include/rankfm_hip.h declares (tests check the library exports all of them)
 EXPORTS = (
     "rfm_abi_version", "rfm_status_string", "rfm_last_error", "rfm_device_count", "rfm_fit_supported",
-    "rfm_fit_workspace_bytes", "rfm_fit_device", "rfm_fit_host", "rfm_predict_device", "rfm_predict_host",
+    "rfm_fit_workspace_bytes", "rfm_fit_device", "rfm_fit_host", "rfm_fit_export_weights", "rfm_predict_device", "rfm_predict_host",
     "rfm_recommend_device", "rfm_recommend_workspace_bytes", "rfm_recommend_host", "rfm_similar_host", "rfm_hbm_probe",
     "rfm_delta_begin", "rfm_delta_finish", "rfm_release_cache",
 )
@@ -148,6 +159,8 @@ def lib():
     L.rfm_fit_workspace_bytes.argtypes = [C.POINTER(FitConfig)]
     L.rfm_fit_device.restype = C.c_int
     L.rfm_fit_device.argtypes = [C.POINTER(FitConfig), C.POINTER(FitBuffers), C.c_void_p, C.POINTER(FitReport)]
+    L.rfm_fit_export_weights.restype = C.c_int
+    L.rfm_fit_export_weights.argtypes = [C.POINTER(FitConfig), C.POINTER(FitBuffers), C.c_void_p]
     L.rfm_fit_host.restype = C.c_int
     L.rfm_fit_host.argtypes = [C.POINTER(FitConfig), C.POINTER(FitBuffers), C.c_int, C.POINTER(FitReport)]
     L.rfm_predict_device.restype = C.c_int

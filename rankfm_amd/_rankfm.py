@@ -40,17 +40,13 @@ class EngineOptions:
     shuffle: str = "device"
     seed: Optional[int] = None
     device: Optional[int] = None
-    n_workgroups: int = 0
-    rows_per_launch: int = 0
     check_finite: bool = True
     damping: float = 0.0          # hogwild step damping M (include/rankfm_hip.h: hogwild_damping); 0 default, < 0 off
-    negative_stripes: bool = False  # OPT-IN fast sampler (include/rankfm_hip.h RFM_SAMPLER_STRIPES): BPR launches that fill the chip draw
-                                    # each window's negatives from an LDS-held stripe of items and publish their updates once per window
-                                    # (DESIGN.md section 3.2).  ~1.5x the update rate, but not the reference's sampler: measured cost 1.0
-                                    # point of hit_rate@10 at 30 k x 12 k and 2.3 points at 100 k x 50 k (profiles/r03_notes.md).  The
-                                    # default draws every negative uniformly over the catalogue like rankfm/_rankfm.pyx:250-253.
+    # experiments / tests only (rfm_fit_tuning; production passes a NULL tuning pointer):
+    n_workgroups: int = 0
+    rows_per_launch: int = 0
     debug_flags: int = 0          # include/rankfm_hip.h: bit 0 = Hogwild kernel on one row group, bit 1 = L1-bypassing loads
-    tune: dict = field(default_factory=dict)   # geometry overrides of rfm_fit_config (_hip.TUNE_FIELDS), experiments only
+    tune: dict = field(default_factory=dict)   # geometry overrides (_hip.TUNE_FIELDS)
 
     def validated(self):
         if self.mode not in ("hogwild", "serial"):
@@ -209,10 +205,10 @@ def _fit(interactions, sample_weight, user_items, x_uf, x_if, w_i, w_if, v_u, v_
         rng_epoch_offset=int(rng_epoch_offset), mode=_hip.MODE_SERIAL if opt.mode == "serial" else _hip.MODE_HOGWILD,
         rng=_hip.RNG_MT19937 if opt.rng == "mt19937" else _hip.RNG_COUNTER, seed=seed & 0xFFFFFFFF,
         check_finite=int(opt.check_finite), want_penalty=int(bool(verbose) or report is not None),
-        n_workgroups=int(opt.n_workgroups), rows_per_launch=int(opt.rows_per_launch),
-        hogwild_damping=float(opt.damping), debug_flags=int(opt.debug_flags),
-        sampler=_hip.SAMPLER_STRIPES if opt.negative_stripes else _hip.SAMPLER_UNIFORM,
-        **_hip.tune_kwargs(opt.tune))
+        hogwild_damping=float(opt.damping))
+    tuning = _hip.make_tuning(opt.tune, n_workgroups=opt.n_workgroups, rows_per_launch=opt.rows_per_launch, debug_flags=opt.debug_flags)
+    if tuning is not None:
+        cfg.tuning = C.pointer(tuning)
     buf = _hip.FitBuffers(
         interactions=_ptr(interactions), sample_weight=_ptr(sample_weight),
         csr_offsets=_ptr(csr.offsets), csr_items=_ptr(csr.items), x_uf=_ptr(x_uf), x_if=_ptr(x_if),

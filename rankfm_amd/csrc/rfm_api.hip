@@ -65,16 +65,50 @@ struct TailArgs {
     unsigned long long len[6];
     double *sumsq;            // [6] or nullptr
     unsigned int *nonfinite;  // bit k set when array k holds a non-finite value
+    int w_stride;             // array 0 (the item biases) is read at ptr[0][i * w_stride]: the engine's padded copy (SgdArgs::w_stride)
+    int drain_hot;            // 1: the launch first folds what the SGD launches left in the hot-row bins into the rows (hot_sweep_line)
 };
 
+// `hot`: the epoch's SgdArgs (read only when t.drain_hot; the fields hot_sweep_line uses).  The drain replaces a kernel launch of its
+// own behind every SGD launch (hot_reduce_kernel, ~4 us + a launch gap per epoch): what a launch's workgroups publish when they
+// leave stays in the bins until the epoch's tail -- or, without a tail, until the next launch's sweeping turns or the export.
+// Finiteness is not affected by where a pending sum sits (the sums are finite by construction: fixed point), the penalty's norms
+// would be: a call that wants them drains with hot_reduce_kernel BEFORE this kernel.
 template <bool PENALTY>
-__global__ void __launch_bounds__(256) tail_kernel(const TailArgs t) {
+__global__ void __launch_bounds__(256) tail_kernel(const TailArgs t, const SgdArgs hot) {
     __shared__ double red[4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (!PENALTY && t.drain_hot) {
+        const int n_lines = hot_lines(hot);
+        for (int line = blockIdx.x * 4 + wid; line < n_lines; line += gridDim.x * 4) hot_sweep_line(hot, line);
+    }
     unsigned bad = 0;
     for (int k = 0; k < 6; ++k) {
         const float *p = t.ptr[k];
         const unsigned long long n = t.len[k];
+        if (k == 0 && t.w_stride > 1) {                     // (the padded biases: one dword per 64-byte line)
+            float acc = 0.0f;
+            unsigned b = 0;
+            for (unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (unsigned long long)gridDim.x * blockDim.x) {
+                const float v = p[idx * (unsigned long long)t.w_stride];
+                b |= ((__float_as_uint(v) & 0x7f800000u) == 0x7f800000u);
+                if (PENALTY) acc += v * v;
+            }
+            if (b) bad |= 1u;
+            if (PENALTY) {
+                double d = (double)acc;
+#pragma unroll
+                for (int m = 32; m > 0; m >>= 1) d += __shfl_xor(d, m);
+                if (lane == 0) red[wid] = d;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const double tot = red[0] + red[1] + red[2] + red[3];
+                    if (tot != 0.0) unsafeAtomicAdd(t.sumsq + k, tot);
+                }
+                __syncthreads();
+            }
+            continue;
+        }
         const unsigned long long n4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (n >> 2) : 0;
         float acc = 0.0f;
         unsigned b = 0;
@@ -192,12 +226,11 @@ __global__ void sw_to_csr_kernel(const int32_t *__restrict__ interactions, const
 struct Workspace {
     float *pos_scale;             // [I]     persistent across calls (plan_is_cached)
     float *sw_csr;                // [N]     persistent
-    int4 *seg_desc;               // [<= U + N / kStripeSegmentRows]  persistent
+    int4 *seg_desc;               // [<= U + N / min_segment_rows]  persistent
     int32_t *hot_item;            // [kMaxHot] persistent
     int32_t *hot_period;          // [kMaxHot] persistent
     unsigned int *sw_max_bits;    // bits of max |sample_weight| (persistent, written with the plan)
     float *feat_ring;             // features kernel: [2 * kFeatMaxProducers] batches of staged steps (never read before written)
-    size_t volatile_offset;       // everything from here on is zeroed at the start of every call
     double *ll;                   // [epochs]
     unsigned long long *draws;    // [epochs]
     double *sumsq;                // [epochs][6]
@@ -205,9 +238,13 @@ struct Workspace {
     unsigned int *error_flags;    // [1] (+pad)
     uint32_t *mt_state;           // [625] (+pad)
     float *multiplier;            // [max_samples + 1]
+    // the ENGINE LAYOUT of the item-side weights, in front of everything that is zeroed per call: a call imports the caller's v_i / w_i into
+    // it and exports them again when it returns, unless the caller keeps the layout between calls (rfm_fit_config.keep_layout)
+    size_t layout_offset;
     float *w_pad;                     // [n_items * kBiasStride] item biases, one 64-byte line each (SgdArgs::w_stride)
-    float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: zero between launches
+    float *hot_bins_v, *hot_bins_w;   // [kHotBins, n_hot, F], [kHotBins, n_hot]: pending hot-row sums (zeroed at import, drained by the epoch tail / the export)
     float *vi_split;                  // [I, F] segment-major working copy of the item factor rows (SgdArgs::vi_split), or nullptr
+    size_t volatile_offset;       // everything from here on is zeroed at the start of every call
     unsigned int *feat_flags;     // [kFeatFlagWords] producer / trainer hand-shake of the features kernel (zero between launches)
     unsigned long long *feat_clock;   // [4] wall-clock ticks of the last launch's tables kernel (begin, end) and row-loop kernel (begin, end)
     unsigned long long *sclk;         // [4] SgdArgs::sclk of the last launch
@@ -217,6 +254,14 @@ struct Workspace {
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// the experiments' overrides of a call (rfm_fit_config.tuning; NULL = production = all zero)
+static rfm_fit_tuning tuning_of(const rfm_fit_config *c) {
+    rfm_fit_tuning t;
+    memset(&t, 0, sizeof t);
+    if (c && c->tuning) t = *c->tuning;
+    return t;
+}
 
 constexpr int kMaxHot = 64;                      // hot-row accumulator slots per workgroup (LDS: kMaxHot * (F + 2) floats)
 // Publications of a hot row per epoch and workgroup (tune_hot_publications).  A publication is not only five atomic requests into the
@@ -236,12 +281,12 @@ constexpr double kHotPublications = 32.0;
 // at 2.4 x), so 2.4 x stays: the tables track the oracle's to 10 % there, and the sparse side (x 2) remains the open end of row a6.
 constexpr double kTableQuotaFactor = 2.4;
 
-constexpr int kStripeSegmentRows = 16;         // segments of a plan that uses negative stripes (see rfm_fit_device, "segment length")
 // (a user of degree d is cut into ceil(d / rows) <= d / rows + 1 segments)
 static size_t max_segments(int64_t n_rows, int n_users, int seg_rows) { return (size_t)n_users + (size_t)(n_rows / seg_rows) + 1; }
-// shortest segment length a plan of this call may use: 16 (stripe plans), or the caller's override when that is shorter
+// shortest segment length a plan of this call may use: kSegmentRows, or the caller's override when that is shorter
 static int min_segment_rows(const rfm_fit_config *c) {
-    return c->tune_segment_rows > 0 && c->tune_segment_rows < kStripeSegmentRows ? c->tune_segment_rows : kStripeSegmentRows;
+    const int rows = tuning_of(c).segment_rows;
+    return rows > 0 && rows < kSegmentRows ? rows : kSegmentRows;
 }
 
 // floats of the features kernel's step ring: 2 slots per producer, one staged step (1 + 2F + P + Q floats) per row group of a
@@ -255,7 +300,8 @@ static size_t feat_ring_floats(const rfm_fit_config *c) {
 
 // launches an epoch can be cut into (rows_per_launch) + the opening launch of a fit with features: every launch has ticket heads of its own
 static int64_t ticket_windows(const rfm_fit_config *c) {
-    const int64_t w = c->rows_per_launch > 0 ? c->n_interactions / c->rows_per_launch + 3 : 2;
+    const int rpl = tuning_of(c).rows_per_launch;
+    const int64_t w = rpl > 0 ? c->n_interactions / rpl + 3 : 2;
     return w < 4096 ? w : 4096;        // (beyond that the launches fall back to the static segment stride)
 }
 
@@ -264,6 +310,7 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     Workspace w;
     char *p = (char *)base;
     size_t o = 0;
+    // ---- the plan: persistent across calls (plan_token)
     w.pos_scale = (float *)(p + o);              o += align_up(sizeof(float) * (size_t)n_items);
     w.sw_csr = (float *)(p + o);                 o += align_up(sizeof(float) * (size_t)(n_rows > 0 ? n_rows : 1));
     w.seg_desc = (int4 *)(p + o);                o += align_up(sizeof(int4) * max_segments(n_rows, n_users, seg_rows_min));
@@ -271,6 +318,15 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.hot_period = (int32_t *)(p + o);           o += align_up(sizeof(int32_t) * kMaxHot);
     w.sw_max_bits = (unsigned int *)(p + o);     o += align_up(sizeof(unsigned int));
     w.feat_ring = (float *)(p + o);              o += align_up(sizeof(float) * n_ring);
+    // ---- the engine layout of the item-side weights: persistent across calls that keep it (layout_token).  Its place must not depend
+    //      on the number of epochs of a call (the arrays behind it do): a kept layout is found again by a call of another length.
+    w.layout_offset = o;
+    w.w_pad = (float *)(p + o);                  o += align_up(sizeof(float) * (size_t)kBiasStride * (size_t)n_items);
+    w.hot_bins_v = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot * (size_t)n_factors);
+    w.hot_bins_w = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot);
+    w.vi_split = vi_split ? (float *)(p + o) : nullptr;
+    if (vi_split) o += align_up(sizeof(float) * (size_t)n_items * (size_t)n_factors);
+    // ---- everything from here on is zeroed at the start of every call
     w.volatile_offset = o;
     w.ll = (double *)(p + o);                    o += align_up(sizeof(double) * epochs);
     w.draws = (unsigned long long *)(p + o);     o += align_up(sizeof(unsigned long long) * epochs);
@@ -282,14 +338,8 @@ static Workspace carve(void *base, int epochs, int max_samples, int n_items, int
     w.mt_state = (uint32_t *)(p + o);            o += align_up(sizeof(uint32_t) * 640);
     w.multiplier = (float *)(p + o);             o += align_up(sizeof(float) * ((size_t)max_samples + 1));
     w.feat_flags = (unsigned int *)(p + o);      o += align_up(sizeof(unsigned int) * kFeatFlagWords);
-    w.w_pad = (float *)(p + o);                  o += align_up(sizeof(float) * (size_t)kBiasStride * (size_t)n_items);
-    w.hot_bins_v = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot * (size_t)n_factors);
-    w.hot_bins_w = (float *)(p + o);             o += align_up(sizeof(float) * (size_t)kHotBins * kMaxHot);
     w.windows_per_epoch = windows_per_epoch;
     w.tickets = (unsigned int *)(p + o);         o += align_up(sizeof(unsigned int) * kTicketWords * (size_t)windows_per_epoch * (size_t)epochs);
-    // (never read before written, never zeroed: last)
-    w.vi_split = vi_split ? (float *)(p + o) : nullptr;
-    if (vi_split) o += align_up(sizeof(float) * (size_t)n_items * (size_t)n_factors);
     w.bytes = o;
     return w;
 }
@@ -303,7 +353,7 @@ static bool vi_split_eligible(const rfm_fit_config *c) {
     //  per-segment addresses cost it two spills: profiles/r05_notes.md.  WARP reads ~23 candidate rows per update: row-major too.)
     // (k = 128: the segment-major instantiation needs more than the 128 registers a 16-wavefront workgroup has -- 31 spilled -- and stays row-major)
     return sh && sh->group == 16 && sh->kpl <= 6 && c->n_factors == sh->group * sh->kpl && c->max_samples == 1 && !c->has_user_features && !c->has_item_features &&
-           c->mode == RFM_MODE_HOGWILD && c->sampler == RFM_SAMPLER_UNIFORM && !(c->debug_flags & 512);
+           c->mode == RFM_MODE_HOGWILD && !(tuning_of(c).debug_flags & 512);
 }
 
 static size_t feat_table_floats(const rfm_fit_config *c) {
@@ -321,17 +371,17 @@ static int validate(const rfm_fit_config *c) {
     if (c->learning_schedule != RFM_SCHEDULE_CONSTANT && c->learning_schedule != RFM_SCHEDULE_INVSCALING)
         return RFM_ERR_UNKNOWN_SCHEDULE;
     if (c->mode != RFM_MODE_HOGWILD && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;
-    if (c->tune_segment_rows < 0 || c->tune_segment_rows > kSegmentRows || c->tune_stripe_window < 0 || c->tune_stripe_window > 4096 ||
-        c->tune_stripe_rows < -1 || c->tune_stripe_rows > 4096 || c->tune_hot_publications < 0 || c->tune_hot_publications > 65536 ||
-        c->tune_feature_waves < 0 || c->tune_feature_waves > 16 || c->tune_table_producers < 0 || c->tune_table_producers > kFeatMaxProducers ||
-        c->tune_table_every < 0 || c->tune_table_step_pct < 0 || c->tune_table_step_pct > 400 ||
-        (c->sampler != RFM_SAMPLER_UNIFORM && c->sampler != RFM_SAMPLER_STRIPES))
+    const rfm_fit_tuning t = tuning_of(c);
+    if (t.segment_rows < 0 || t.segment_rows > kSegmentRows || t.hot_publications < 0 || t.hot_publications > 65536 ||
+        t.feature_waves < 0 || t.feature_waves > 16 || t.table_producers < 0 || t.table_producers > kFeatMaxProducers ||
+        t.table_every < 0 || t.table_step_pct < 0 || t.table_step_pct > 400 || t.table_batch < 0 || t.table_batch > 256 || (t.table_batch & 3) ||
+        t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0)
         return RFM_ERR_BAD_ARG;
+    if (c->keep_layout != 0 && c->keep_layout != 1) return RFM_ERR_BAD_ARG;
+    if (c->layout_token < 0 || (c->layout_token != 0 && c->plan_token <= 0)) return RFM_ERR_BAD_ARG;      // (a kept layout lives with its plan)
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
     if (c->rng == RFM_RNG_MT19937 && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;   // one serial stream
     if (!pick_shape(c->n_factors)) return RFM_ERR_UNSUPPORTED;
-    // (a library built without the opt-in stripe sampler, RFM_NO_STRIPES)
-    if (c->sampler == RFM_SAMPLER_STRIPES && !pick_shape(c->n_factors)->table()[10]) return RFM_ERR_UNSUPPORTED;
     return RFM_OK;
 }
 
@@ -542,9 +592,41 @@ int rfm_fit_device(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hi
     return fit_device_impl(cfg, b, hip_stream, rep, nullptr);
 }
 
+int rfm_fit_export_weights(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream) {
+    int rc = validate(cfg);
+    if (rc != RFM_OK) return rc;
+    if (!b || !b->w_i || !b->v_i || !b->workspace) return RFM_ERR_BAD_ARG;
+    if (cfg->layout_token == 0) return RFM_OK;
+    const Workspace ws = carve(b->workspace, cfg->epochs, cfg->max_samples, cfg->n_items, cfg->n_users, cfg->n_interactions, feat_ring_floats(cfg), cfg->n_factors,
+                               min_segment_rows(cfg), ticket_windows(cfg), vi_split_eligible(cfg));
+    if (b->workspace_bytes < ws.volatile_offset) return RFM_ERR_WORKSPACE;      // (the plan and the layout: what this call touches)
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const bool pad = (cfg->layout_token & 2) != 0, split = (cfg->layout_token & 4) != 0;
+    const int n_hot = (int)((cfg->layout_token >> 8) & 0xFF);
+    if (!(cfg->layout_token & 1) || (split && !ws.vi_split) || n_hot > kMaxHot) return RFM_ERR_BAD_ARG;
+    if (n_hot > 0) {
+        SgdArgs a;
+        memset(&a, 0, sizeof a);
+        a.v_i = split ? ws.vi_split : b->v_i; a.w_i = pad ? ws.w_pad : b->w_i; a.w_stride = pad ? kBiasStride : 1;
+        a.n_items = cfg->n_items; a.n_factors = cfg->n_factors; a.vi_split = split ? 1 : 0;
+        a.hot_item = ws.hot_item; a.n_hot = n_hot; a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w;
+        const int lines = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16;
+        hipLaunchKernelGGL(hot_reduce_kernel, dim3((lines + 3) / 4), dim3(256), 0, stream, a);
+    }
+    if (pad) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);
+    if (split) {
+        const int vi_segs = cfg->n_factors / 16;
+        const int vi_grid = (int)std::min<size_t>(4096, ((size_t)cfg->n_items * vi_segs * 4 + 255) / 256);
+        vi_split_kernel<false><<<dim3(vi_grid), dim3(256), 0, stream>>>((float4 *)b->v_i, (float4 *)ws.vi_split, cfg->n_items, vi_segs);
+    }
+    RFM_HIP(hipGetLastError());
+    return RFM_OK;
+}
+
 static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, void *hip_stream, rfm_fit_report *rep, const int64_t *host_offsets) {
     int rc = validate(cfg);
     if (rc != RFM_OK) return rc;
+    const rfm_fit_tuning T = tuning_of(cfg);
     if (!b || !b->interactions || !b->sample_weight || !b->csr_offsets || !b->csr_items || !b->x_uf || !b->x_if ||
         !b->w_i || !b->w_if || !b->v_u || !b->v_i || !b->v_uf || !b->v_if)
         return RFM_ERR_BAD_ARG;
@@ -556,7 +638,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     if (!b->workspace || b->workspace_bytes < ws.bytes) return RFM_ERR_WORKSPACE;
     hipStream_t stream = (hipStream_t)hip_stream;
     const ShapeEntry *shape = pick_shape(cfg->n_factors);
-    if (cfg->debug_shape > 0 && cfg->debug_shape <= (int)(sizeof(kShapes) / sizeof(kShapes[0]))) shape = &kShapes[cfg->debug_shape - 1];
+    if (T.debug_shape > 0 && T.debug_shape <= (int)(sizeof(kShapes) / sizeof(kShapes[0]))) shape = &kShapes[T.debug_shape - 1];
     if (shape->max_f < cfg->n_factors) return RFM_ERR_BAD_ARG;          // (a debug_shape too narrow for the factor rows)
     const bool serial = cfg->mode == RFM_MODE_SERIAL;
     const bool feat = cfg->has_user_features || cfg->has_item_features;
@@ -572,9 +654,8 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     std::vector<float> mult((size_t)cfg->max_samples + 1, 0.0f);
     for (int s = 1; s <= cfg->max_samples; ++s)
         mult[s] = (float)(log((double)((cfg->n_items - 1) / s)) / log((double)cfg->n_items));
-    // (the segment-major copy of the item rows at the workspace's end is written before it is read: not zeroed)
-    const size_t zero_end = ws.vi_split ? (size_t)((const char *)ws.vi_split - (const char *)b->workspace) : ws.bytes;
-    RFM_HIP(hipMemsetAsync((char *)b->workspace + ws.volatile_offset, 0, zero_end - ws.volatile_offset, stream));
+    // (the engine layout of the item-side weights in front of it is imported below, or kept from the previous call)
+    RFM_HIP(hipMemsetAsync((char *)b->workspace + ws.volatile_offset, 0, ws.bytes - ws.volatile_offset, stream));
     RFM_HIP(hipMemcpyAsync(ws.multiplier, mult.data(), mult.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     std::vector<uint32_t> mt(625);
     if (cfg->rng == RFM_RNG_MT19937) {
@@ -591,22 +672,10 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     // ---- plan, part 1 (segments kernel): user segments.  A user of degree d is cut into ceil(d / 32) near-equal runs of
     //      consecutive CSR positions; descriptors {user, first position, length} are built on the host from the offsets.
     //      The plan lives in the persistent head of the workspace; `plan_token` (= segment count) says it is still valid.
-    // Segment length.  With negative stripes a user's segment should span several (workgroup, window) slots: all negatives of the
-    // rows inside one slot come from the same ~190 items, and what a user is contrasted with inside an epoch is what the ranking
-    // quality depends on (CPU model, profiles/r02_notes.md: 32-row segments cost ~1.3 points of hit_rate@10 at 30,000 x 12,000 even
-    // in the SEQUENTIAL algorithm, 16-row segments 0.3).  So the plan is cut into 16-row segments when stripes are going to be
-    // used -- decided here, before the plan, from everything the later `use_stripes` depends on except the plan itself.
     const float damp_m = cfg->hogwild_damping == 0.0f ? 128.0f : cfg->hogwild_damping;
-    const bool one_group_flag = (cfg->debug_flags & 1) != 0;
-    bool want_stripes = use_segments && !feat && cfg->sampler == RFM_SAMPLER_STRIPES && !(cfg->debug_flags & 8) &&
-                        cfg->max_samples == 1 && cfg->n_factors == shape->group * shape->kpl &&
-                        (one_group_flag || (damp_m > 0.0f && N > 0));
-    if (want_stripes && !one_group_flag && cfg->n_workgroups <= 0) {
-        const long long cap_groups = std::min<long long>(N / 128, (long long)std::min(cfg->n_users, cfg->n_items) / 3);
-        if (cap_groups < 32LL * 16 * (64 / shape->group)) want_stripes = false;
-    }
-    int seg_rows = want_stripes ? kStripeSegmentRows : kSegmentRows;
-    if (cfg->tune_segment_rows > 0) seg_rows = std::min(kSegmentRows, cfg->tune_segment_rows);
+    const bool one_group_flag = (T.debug_flags & 1) != 0;
+    int seg_rows = kSegmentRows;
+    if (T.segment_rows > 0) seg_rows = std::min(kSegmentRows, T.segment_rows);
     // plan_token = segment count | hot-slot count << 40 | segment length << 48; a plan cut for another segment length is rebuilt
     const bool token_plan = cfg->plan_token > 0 && cfg->plan_token != kRowsPlan;
     const bool have_plan = token_plan && (int)((cfg->plan_token >> 48) & 0xFF) == seg_rows;
@@ -694,7 +763,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             return RFM_ERR_USER_SATURATED;
         }
     }
-    const bool single_group = use_segments && one_group_flag, fresh = (cfg->debug_flags & 2) != 0;
+    const bool single_group = use_segments && one_group_flag, fresh = (T.debug_flags & 2) != 0;
     const bool damp = !serial && !single_group && damp_m > 0.0f && N > 0;
 
     // ---- plan, part 2: item popularity (positive occurrences per item), needed by the damping and by the hot-row choice
@@ -712,7 +781,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     //  at most 32 + 32 features)
     const bool feat_fast = feat && shape->group == 16 && cfg->max_samples == 1 && cfg->n_user_features <= 32 && cfg->n_item_features <= 32;
     std::vector<int> hot_order;
-    if (damp && build_plan && use_segments && (!feat || feat_fast) && !(cfg->debug_flags & 4)) {
+    if (damp && build_plan && use_segments && (!feat || feat_fast) && !(T.debug_flags & 4)) {
         // (interactions in flight: the full-chip geometry, or what the concurrency caps of the geometry below leave of it -- on a
         // small problem a popular item is touched by a handful of concurrent updates at most, and accumulating it would only
         // delay its updates: measured on the 3000 x 2000 feature-model fixture, |w_i| -4.6 % with, -0.8 % without)
@@ -728,19 +797,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         n_hot = (int)hot_order.size();
     }
     const bool use_hot = use_segments && (!feat || feat_fast) && !single_group && n_hot > 0;
-    // Negative stripes (rfm_sgd.hpp, STRIPE; include/rfm_rng.h): the production path without features.  debug_flags bit 3 falls back to whole-catalogue draws with one set of atomics per negative.
-    // BPR only: WARP's candidate screening inside a stripe (up to 50 draws WITH replacement from ~200 items) changes the
-    // statistics of the rank estimate -- against the sequential oracle the log-likelihood moved by -5 % at a 12-row window --
-    // and the WARP instantiation gained no time from it (the experiment's instantiations left the tree in round 4).
-    // Full factor rows only (n_factors == lanes per group x dwords per lane: 16, 32, 48, 64, 96, 128, ...): the stripe
-    // instantiations carry no per-dword bounds predicate.
-    // (decided before the plan was cut -- `want_stripes`, "Segment length" above -- including the size condition: launches that
-    // do not fill a good part of the chip are nowhere near the atomic ceiling, their time is memory latency, and delayed
-    // publication only costs them accuracy; one group alone keeps the stripes: that is the sequential form of the production
-    // kernel the parity tests pin to the oracle.  Undamped Hogwild on skewed data needs every push published at once: notes.)
-    const bool use_stripes = want_stripes && use_segments;
-    const sgd_launch_fn launch = use_stripes ? shape->table()[10 + (fresh ? 1 : 0) + (use_hot ? 2 : 0)]
-                                 : (use_hot && !feat) ? shape->table()[8 + (fresh ? 1 : 0)]
+    const sgd_launch_fn launch = (use_hot && !feat) ? shape->table()[8 + (fresh ? 1 : 0)]
                                  : use_segments ? shape->table()[4 + (feat ? 1 : 0) + (fresh ? 2 : 0)]
                                                 : shape->table()[(serial ? 2 : 0) + (feat ? 1 : 0)];
 
@@ -749,32 +806,25 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     const int groups_per_wave = serial ? 1 : 64 / shape->group;
     // features kernel: 16 wavefronts per workgroup share one LDS copy of the tables (<= 64 KB, checked above)
     int feat_waves = 16;
-    if (cfg->tune_feature_waves > 0) feat_waves = std::max(2, std::min(16, cfg->tune_feature_waves));
+    if (T.feature_waves > 0) feat_waves = std::max(2, std::min(16, T.feature_waves));
     // (the table trainer also stages one step per row group: 1 + 2F + P + Q floats each; wide tables take smaller workgroups)
     while (feat_waves > 2 && sizeof(float) * (feat_table_floats(cfg) + 8 + (size_t)feat_waves * (64 / shape->group) *
                                               (5 + 2 * (size_t)shape->group * shape->kpl + cfg->n_user_features + cfg->n_item_features)) > kLdsBytes)
         feat_waves /= 2;
     // (the tables kernel keeps `feat_waves`; the pipelined row loop runs 12 wavefronts per workgroup -- three per SIMD, 168 registers:
     //  at 16 it has 128 and spills a third of its working set, rfm_sgd.hpp -- unless the caller overrides)
-    const int table_waves = feat_waves;
-    if (use_segments && feat && feat_fast && cfg->tune_feature_waves == 0 && !single_group) feat_waves = std::min(feat_waves, 12);
-    const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : ((use_hot || use_stripes) ? 16 : 4));   // see sgd_segments_kernel
-    // stripe geometry: as many rows as the LDS left by the hot-row accumulators holds (at most 256: more rows mean longer
-    // windows for the same combining), and a window in which a stripe row receives ~8 updates (groups x window / rows)
-    int stripe_rows = 0, stripe_window = 1, stripe_rows_cap = 0;
-    if (use_stripes) {
-        const size_t budget = 156 * 1024 - sizeof(float) * (use_hot ? (size_t)n_hot * (cfg->n_factors + 2) : 0);
-        stripe_rows = (int)std::min<size_t>(256, (budget - sizeof(float) * ((size_t)cfg->n_factors + 1)) / (sizeof(float) * (1 + 2 * ((size_t)cfg->n_factors + 1))));
-        stripe_rows = std::max(1, std::min(stripe_rows, cfg->n_items));
-        stripe_rows_cap = stripe_rows;
-    }
+    // (a batch of the table trainer = one staged step per row group of the tables kernel's workgroup: `table_batch` sizes that workgroup)
+    int table_waves = feat_waves;
+    if (T.table_batch > 0) table_waves = std::max(1, std::min(feat_waves, T.table_batch * shape->group / 64));
+    if (use_segments && feat && feat_fast && T.feature_waves == 0 && !single_group) feat_waves = std::min(feat_waves, 12);
+    const int waves_per_block = serial ? 1 : (use_segments && feat ? feat_waves : (use_hot ? 16 : 4));   // see sgd_segments_kernel
     int grid = 1, n_producers = 0;
-    const bool feat_frozen = (cfg->debug_flags & 32) != 0;
+    const bool feat_frozen = (T.debug_flags & 32) != 0;
     int64_t max_groups = 0;
     int64_t units_per_launch = units > 0 ? units : 1;
     if (!serial) {
-        if (cfg->rows_per_launch > 0 && cfg->rows_per_launch < N) {
-            units_per_launch = use_segments ? (int64_t)((double)cfg->rows_per_launch * (double)units / (double)N) : cfg->rows_per_launch;
+        if (T.rows_per_launch > 0 && T.rows_per_launch < N) {
+            units_per_launch = use_segments ? (int64_t)((double)T.rows_per_launch * (double)units / (double)N) : T.rows_per_launch;
             if (units_per_launch < 1) units_per_launch = 1;
         }
         const int64_t groups_per_block = (int64_t)groups_per_wave * waves_per_block;
@@ -791,7 +841,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // run 2.61 / 2.63 / 2.60 ms against 2.63 / 2.66 / 2.66 at 256 (224: 2.64 / 2.66 / 2.61; 160 and fewer: slower), with a quarter
         // fewer rows in flight -- the asynchrony term of the ranking quality scales with those (-1.9 point at 16 k in
         // flight against the oracle in the engine's order, -1.2 at 12 k) -- and a quarter fewer hot-row publications.
-        if (use_hot && !feat && cfg->max_samples == 1 && cfg->n_workgroups <= 0) cap = cap * 3 / 4;
+        if (use_hot && !feat && cfg->max_samples == 1 && T.n_workgroups <= 0) cap = cap * 3 / 4;
         // (feature launches: ONE workgroup per CU whatever its size -- the 12-wavefront row loop takes three wavefronts per SIMD and no
         //  second workgroup fits beside it; the trainer, its producers and the row loops must all be resident)
         if (use_segments && feat) cap = std::min<int64_t>(cap, g_sm_count > 0 ? g_sm_count : 256);
@@ -807,8 +857,8 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         max_groups = N / 128 < (int64_t)(cfg->n_users < cfg->n_items ? cfg->n_users : cfg->n_items) / 3
                          ? N / 128 : (int64_t)(cfg->n_users < cfg->n_items ? cfg->n_users : cfg->n_items) / 3;
         if (max_groups < 1) max_groups = 1;
-        if (cfg->n_workgroups > 0) max_groups = 0;          // explicit geometry: no cap
-        if (cfg->n_workgroups > 0) cap = cfg->n_workgroups;
+        if (T.n_workgroups > 0) max_groups = 0;          // explicit geometry: no cap
+        if (T.n_workgroups > 0) cap = T.n_workgroups;
         grid = (int)(need < cap ? need : cap);
         if (grid < 1 || single_group) grid = 1;
         // features kernel: workgroup 0 is the table trainer and workgroups 1 .. n_producers stage the steps it applies
@@ -820,7 +870,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         if (use_segments && feat && !single_group && !feat_frozen) {
             const int64_t room = std::max<int64_t>(cap, 3);
             n_producers = grid >= 64 ? 3 : (grid >= 4 ? 2 : 1);
-            if (cfg->tune_table_producers > 0) n_producers = std::min(kFeatMaxProducers, cfg->tune_table_producers);
+            if (T.table_producers > 0) n_producers = std::min(kFeatMaxProducers, T.table_producers);
             // the trainer, its producers and at least one row loop must all be RESIDENT (they hand-shake by spinning): never more
             // producers than the launch's room leaves beside one trainer and one row-loop workgroup
             n_producers = (int)std::max<int64_t>(1, std::min<int64_t>(n_producers, room - 2));
@@ -841,45 +891,6 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         }
     }
     const int launches = (int)((units + units_per_launch - 1) / units_per_launch);
-    if (use_stripes) {
-        // concurrent windows should hold DISJOINT stripes (then a stripe row's exact view misses nothing but in-flight
-        // updates): at least as many stripes as workgroups.  A window lets a stripe row combine ~10 updates into one
-        // publication (groups x window / rows), at most 32 rows per group.
-        const int gpb = waves_per_block * groups_per_wave;
-        // Window length.  A stripe row's updates stay in LDS until its window ends: at any time the last ~window / 2 rows of
-        // every working group are unpublished, (groups x window / 2) / I pending DOWNWARD pushes per item that the rest of the
-        // chip does not see.  What that costs depends on the view a step takes of its two items (profiles/r02_notes.md): if
-        // the negative is seen with the workgroup's own pending pushes while the positive -- whose pending pushes sit in some
-        // other workgroup's LDS -- is seen without them, every pairwise utility is overestimated and the log-likelihood
-        // drifts from the sequential oracle's in proportion to the window (config 2: -0.3 / -2.3 / -5.8 % at 8 / 16 / 32 rows);
-        // with BOTH items seen as published (RowStep::fetch_item) the staleness is symmetric and the log-likelihood no longer
-        // moves with the window (+1.7 / +1.6 / +1.7 %, +1.2 % without stripes), only the norms creep up (+0.5 -> +0.9 % on v_i)
-        // as several pushes of a window start from the same published value.  With the positive's view corrected by the stripe's
-        // mean pending sum (the committed form, RowStep::sn_sum) the measured log-likelihood against the sequential oracle on
-        // config 2 is, epochs 1 / 2 (tools/c2_ll_ratio.py): 6 rows +2.1 / +1.4 %, 8 rows +1.9 / +1.3 %, 12 rows +1.6 ... +1.8 /
-        // +0.9 ... +1.1 %, 16 rows +1.6 / +0.8 %, 24 rows +1.0 / +0.2 % (|w_i| -0.6 %, |v_i| +0.15 %), +1.1 / +0.8 % without
-        // stripes; kernel 2.45 / 2.25 / 2.15 / 2.12 / 2.0 ms.  Window = 8 I / groups rows (<= 32; 24 on config 2): ~4 pending
-        // pushes per item, where the two opposite biases of delayed publication leave the widest margin to the 2 % bar on both
-        // sides; stripe = groups x window / 2 rows (<= 256): a smaller stripe would combine more pushes per publication but
-        // concentrates the pending pushes on fewer rows, and the atomics no longer bound the kernel.
-        const long long g_work = single_group ? 1 : std::min<long long>((long long)grid * gpb, max_groups > 0 ? max_groups : (1LL << 60));
-        stripe_window = (int)std::max<long long>(1, std::min<long long>(32, (long long)(8.0 * (double)cfg->n_items / (double)g_work + 0.5)));
-        if (cfg->tune_stripe_window > 0) stripe_window = cfg->tune_stripe_window;
-        if (single_group) stripe_window = 1;      // one group alone: a fresh stripe for every row keeps it exactly sequential
-        const int combine = 2;
-        int want_rows = std::max(16, (int)std::min<long long>(g_work, gpb) * stripe_window / combine);
-        if (cfg->tune_stripe_rows != 0) want_rows = std::max(0, cfg->tune_stripe_rows);      // (-1: no stripe, pipelined row loop only)
-        stripe_rows = std::max(want_rows > 0 ? 1 : 0, std::min(std::min(stripe_rows_cap, want_rows), cfg->n_items / (single_group ? 1 : grid)));
-        // consecutive windows of one workgroup start grid x rows positions apart (include/rfm_rng.h): keep that step, taken
-        // around the cycle of I positions, at least a stripe long so that they do not overlap
-        if (!single_group && stripe_rows > 0 && cfg->n_items >= 2 * stripe_rows)
-            while (stripe_rows > 1) {
-                const long long step = ((long long)grid * stripe_rows) % cfg->n_items;
-                if (step >= stripe_rows && step <= cfg->n_items - stripe_rows) break;
-                --stripe_rows;
-            }
-    }
-
     // ---- plan, part 3: Hogwild damping.  n(row) = interactions in flight x the row's share of the data (+ what the other
     //      workgroups hold unpublished for a hot row); scale = min(1, M / n)
     long long in_flight = single_group ? 1 : (long long)(grid - (n_producers > 0 ? 1 + n_producers : 0)) * waves_per_block * groups_per_wave;
@@ -895,7 +906,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         }
         std::vector<int32_t> h_item(kMaxHot, 0), h_period(kMaxHot, 1);
         // (BPR without features: 32, measured; WARP and the features kernels keep the 48 their parity figures were measured with)
-        const double hot_pubs = cfg->tune_hot_publications > 0 ? (double)cfg->tune_hot_publications : (cfg->max_samples == 1 && !feat ? kHotPublications : 48.0);
+        const double hot_pubs = T.hot_publications > 0 ? (double)T.hot_publications : (cfg->max_samples == 1 && !feat ? kHotPublications : 48.0);
         for (int s = 0; s < (use_hot ? n_hot : 0); ++s) {
             const int i = hot_order[s];
             // publish about kHotPublications times per epoch and workgroup: ~3 % of the row's updates are pending chip-wide at any time
@@ -914,46 +925,79 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         RFM_HIP(hipStreamSynchronize(stream));              // pageable host vectors
     }
 
-    // Hogwild launches work on the padded copy of the item biases; it is written back after every epoch (the tail kernel
-    // and the caller read w_i)
+    // Hogwild launches work on a padded copy of the item biases (one 64-byte line each; the epoch tail reads it in place)
     // (WARP reads a bias per candidate, ~20 per update: there the 16x larger table costs more in read misses than the
     // atomics gain -- config 3: 318 M updates/s unpadded, 306 M padded -- so only BPR-like sampling pads)
-    // (with stripes the candidates' biases are LDS reads, so WARP pads as well)
-    const bool pad_bias = !serial && (use_stripes || cfg->max_samples <= 4);
-    if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, damp ? ws.pos_scale : nullptr, cfg->n_items);
+    const bool pad_bias = !serial && cfg->max_samples <= 4;
     // Chip-filling BPR launches with hot-row accumulators (the launches that sit at the memory-side atomic path's capacity) work on a
-    // segment-major copy of the item factor rows for the length of the call (SgdArgs::vi_split); the caller's v_i is written back
-    // behind the last epoch.  The epoch tail reads the copy: its sums and its finiteness check do not depend on the order of the elements.
-    const bool vi_split = ws.vi_split && use_hot && !feat && !use_stripes && !single_group && vi_split_eligible(cfg);
+    // segment-major copy of the item factor rows (SgdArgs::vi_split).  The epoch tail reads the copy: its sums and its finiteness
+    // check do not depend on the order of the elements.
+    const bool vi_split = ws.vi_split && use_hot && !feat && !single_group && vi_split_eligible(cfg);
     const int vi_segs = cfg->n_factors / 16;
     const int vi_grid = (int)std::min<size_t>(4096, ((size_t)cfg->n_items * vi_segs * 4 + 255) / 256);
-    if (vi_split) vi_split_kernel<true><<<dim3(vi_grid), dim3(256), 0, stream>>>((float4 *)b->v_i, (float4 *)ws.vi_split, cfg->n_items, vi_segs);
+    // ---- the engine layout of the item-side weights (padded biases, segment-major rows, hot-row bins): imported from the caller's
+    //      arrays now, unless the previous call on this workspace kept it (layout_token) -- then the workspace holds the current
+    //      weights and the caller's v_i / w_i are stale.  layout token = 1 | padded biases << 1 | segment-major rows << 2 | hot slots << 8.
+    const int64_t layout_kind = 1 | (pad_bias ? 2 : 0) | (vi_split ? 4 : 0) | ((int64_t)(use_hot ? n_hot : 0) << 8);
+    const bool layout_live = cfg->layout_token != 0;
+    if (layout_live && (build_plan || cfg->layout_token != layout_kind)) {
+        g_last_error = "layout_token: the workspace does not hold this call's engine layout (another plan, geometry or model kind)";
+        return RFM_ERR_BAD_ARG;
+    }
+    if (!layout_live) {
+        if (use_hot) RFM_HIP(hipMemsetAsync(ws.hot_bins_v, 0, (size_t)((const char *)(ws.hot_bins_w + (size_t)kHotBins * kMaxHot) - (const char *)ws.hot_bins_v), stream));
+        if (pad_bias) bias_pad_kernel<true><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, damp ? ws.pos_scale : nullptr, cfg->n_items);
+        if (vi_split) vi_split_kernel<true><<<dim3(vi_grid), dim3(256), 0, stream>>>((float4 *)b->v_i, (float4 *)ws.vi_split, cfg->n_items, vi_segs);
+    }
+    // the way back (the end of a call that does not keep the layout; rfm_fit_export_weights): pending hot-row sums into the rows, then
+    // the two copies into the caller's arrays
+    SgdArgs hot_args;                 // (the last epoch's arguments: what hot_sweep_line reads)
+    memset(&hot_args, 0, sizeof hot_args);
+    auto export_layout = [&]() {
+        if (use_hot) hipLaunchKernelGGL(hot_reduce_kernel, dim3((n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 + 3) / 4), dim3(256), 0, stream, hot_args);
+        if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);
+        if (vi_split) vi_split_kernel<false><<<dim3(vi_grid), dim3(256), 0, stream>>>((float4 *)b->v_i, (float4 *)ws.vi_split, cfg->n_items, vi_segs);
+    };
     // timing events: destroyed on every exit path
     struct Events {
         std::vector<hipEvent_t> ev;
         ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
     } events;
     std::vector<hipEvent_t> &ev = events.ev;
-    ev.assign((size_t)2 * E, nullptr);
+    ev.assign((size_t)2 * E + 1, nullptr);
     const bool timing = rep && rep->sgd_kernel_ms;
     if (timing)
-        for (auto &e : ev) RFM_HIP(hipEventCreate(&e));
+        for (size_t k = 0; k < (size_t)2 * E; ++k) RFM_HIP(hipEventCreate(&ev[k]));
     // The reference stops at the first epoch that ends non-finite (assert_finite, rankfm/_rankfm.pyx:329).  Epochs are
-    // enqueued without waiting; every kCheckEvery epochs the host looks at the flags the tail kernels have written so far
-    // (one 4-byte read-back) and stops launching once one is set, instead of training on NaN for the rest of the call.
+    // enqueued without waiting; every kCheckEvery epochs the flags the tail kernels have written so far are copied to pinned host
+    // memory behind the work already queued, and the copy issued kCheckEvery epochs EARLIER -- long complete unless the host runs that
+    // far ahead of the device -- is looked at: launching stops once a flag is set, instead of training on NaN for the rest of the
+    // call, and the device never waits for the host (a blocking read-back here idled it for a launch latency every eighth epoch).
     constexpr int kCheckEvery = 8;
     int epochs_launched = 0;
+    struct Probe {
+        unsigned int *host = nullptr;
+        ~Probe() { if (host) (void)hipHostFree(host); }
+    } probe;
+    hipEvent_t &probe_ev = ev[(size_t)2 * E];
+    int probed = 0;                   // epochs covered by the copy in flight (0: none)
+    if (cfg->check_finite && E > kCheckEvery) {
+        RFM_HIP(hipHostMalloc((void **)&probe.host, sizeof(unsigned int) * ((size_t)E + 16), hipHostMallocDefault));
+        RFM_HIP(hipEventCreateWithFlags(&probe_ev, hipEventDisableTiming));
+    }
 
     for (int e = 0; e < E; ++e) {
-        if (cfg->check_finite && e > 0 && e % kCheckEvery == 0) {
-            std::vector<unsigned int> seen((size_t)e);
-            unsigned int err = 0;
-            RFM_HIP(hipMemcpyAsync(seen.data(), ws.nonfinite, sizeof(unsigned int) * e, hipMemcpyDeviceToHost, stream));
-            RFM_HIP(hipMemcpyAsync(&err, ws.error_flags, sizeof err, hipMemcpyDeviceToHost, stream));
-            RFM_HIP(hipStreamSynchronize(stream));
-            bool stop = (err & 3u) != 0;
-            for (unsigned int f : seen) stop |= f != 0;
-            if (stop) break;
+        if (probe.host && e > 0 && e % kCheckEvery == 0) {
+            if (probed > 0) {
+                RFM_HIP(hipEventSynchronize(probe_ev));
+                bool stop = (probe.host[E] & 3u) != 0;
+                for (int k = 0; k < probed; ++k) stop |= probe.host[k] != 0;
+                if (stop) break;
+            }
+            RFM_HIP(hipMemcpyAsync(probe.host, ws.nonfinite, sizeof(unsigned int) * e, hipMemcpyDeviceToHost, stream));
+            RFM_HIP(hipMemcpyAsync(probe.host + E, ws.error_flags, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+            RFM_HIP(hipEventRecord(probe_ev, stream));
+            probed = e;
         }
         epochs_launched = e + 1;
         const int epoch = cfg->epoch_begin + e;
@@ -977,20 +1021,17 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w; a.sw_max_bits = ws.sw_max_bits;
         // (sweeping workgroups: all of them, or the row-loop workgroups of the features kernel)
         a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * (grid - (n_producers > 0 ? 1 + n_producers : 0)) ? 1 : 0;   // see SgdArgs::hot_bins_v
-        a.stripe_rows = stripe_rows; a.stripe_window = stripe_window;
-        a.item_bits = rfm_perm_bits((uint32_t)cfg->n_items);
         a.launch_index = 0;
-        a.stripe_cover = stripe_rows > 0 ? std::min(1.0f, (float)grid * (float)stripe_rows / (float)cfg->n_items) : 0.0f;
         a.block_threads = waves_per_block * 64;
         a.table_threads = table_waves * 64;
         a.feat_ring = ws.feat_ring; a.feat_flags = ws.feat_flags; a.n_producers = n_producers; a.feat_frozen = feat_frozen ? 1 : 0;
         a.tickets = nullptr;
-        a.damp_positive_only = (cfg->debug_flags & 256) ? 1 : 0;
+        a.damp_positive_only = (T.debug_flags & 256) ? 1 : 0;
         a.vi_split = vi_split ? 1 : 0;
         a.feat_clock = ws.feat_clock;
         a.sclk = ws.sclk;
         a.table_quota = 0;
-        a.table_step = cfg->tune_table_step_pct > 0 ? (float)cfg->tune_table_step_pct * 0.01f : 1.0f;
+        a.table_step = T.table_step_pct > 0 ? (float)T.table_step_pct * 0.01f : 1.0f;
         a.table_quiet_from = 0.0f;
         // table trainer: steps to apply in a launch of `n_units` segments beside `rowloop_wgs` row-loop workgroups.  A row-loop workgroup
         // walks about as many rows per second as the trainer applies steps (profiles/r03_notes.md section 7), so a trainer that works
@@ -1012,14 +1053,14 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             if (max_groups > 0) rowloop_groups = std::min(rowloop_groups, (double)max_groups);
             if (rowloop_groups < 4096.0) factor = std::min(factor, 1.8);
             const double every_default = std::max(1.0, factor * rowloop_groups / 64.0);
-            const double every = cfg->tune_table_every > 0 ? (double)cfg->tune_table_every : every_default;
+            const double every = T.table_every > 0 ? (double)T.table_every : every_default;
             // a caller's quota DENSER than the default gets the trainer's own stop (kTableQuietFrom); the default and anything sparser
             // are done long before it and keep their exact, repeatable step count
-            if (quiet_from) *quiet_from = (cfg->tune_table_every > 0 && every < every_default) ? kTableQuietFrom : 0.0f;
+            if (quiet_from) *quiet_from = (T.table_every > 0 && every < every_default) ? kTableQuietFrom : 0.0f;
             return (int64_t)(rows / every);
         };
         // ticket heads of launch `w` of this epoch (dynamic segment order; debug_flags bit 7 keeps the static stride)
-        const bool use_tickets = use_segments && !use_stripes && !single_group && !(cfg->debug_flags & 128);
+        const bool use_tickets = use_segments && !single_group && !(T.debug_flags & 128);
         auto tickets_of = [&](int w) -> unsigned int * {
             return use_tickets && w < ws.windows_per_epoch ? ws.tickets + ((size_t)e * ws.windows_per_epoch + w) * kTicketWords : nullptr;
         };
@@ -1059,7 +1100,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         const int n_rowloops = grid - 1 - n_producers;
         const int head_rowloops = std::max(1, std::min(16, n_rowloops / 8));
         if (use_segments && feat && !single_group && !feat_frozen && n_producers > 0 && epoch == 0 && cfg->rng_epoch_offset == 0 && u_begin == 0 &&
-            n_rowloops >= 2 * head_rowloops && !(cfg->debug_flags & 64)) {
+            n_rowloops >= 2 * head_rowloops && !(T.debug_flags & 64)) {
             const double memory = 1.0 / std::max(1e-6, (double)a.reg_b * (double)a.eta);
             const double frac = std::min(1.0 / 16.0, 500.0 * memory / (double)N);
             head_units = std::max<int64_t>(1, (int64_t)((double)units * frac));
@@ -1085,12 +1126,14 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, kTableQuotaFactor, &a.table_quiet_from);
             launch(a, grid, stream);
         }
-        if (pad_bias) bias_pad_kernel<false><<<dim3((cfg->n_items + 255) / 256), dim3(256), 0, stream>>>(b->w_i, ws.w_pad, nullptr, cfg->n_items);
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));
+        hot_args = a;
 
         if (cfg->check_finite || cfg->want_penalty) {
+            // the epoch tail works on the engine's layout in place: the padded biases (strided), the segment-major rows (its sums do not
+            // depend on the order of the elements), and -- in the same launch -- folds the pending hot-row sums into the rows
             TailArgs t;
-            const float *ptrs[6] = {b->w_i, b->w_if, b->v_u, vi_split ? ws.vi_split : b->v_i, b->v_uf, b->v_if};
+            const float *ptrs[6] = {pad_bias ? ws.w_pad : b->w_i, b->w_if, b->v_u, vi_split ? ws.vi_split : b->v_i, b->v_uf, b->v_if};
             const unsigned long long lens[6] = {
                 (unsigned long long)cfg->n_items, (unsigned long long)cfg->n_item_features,
                 (unsigned long long)cfg->n_users * cfg->n_factors, (unsigned long long)cfg->n_items * cfg->n_factors,
@@ -1100,14 +1143,21 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             for (int k = 0; k < 6; ++k) { t.ptr[k] = ptrs[k]; t.len[k] = lens[k]; total += lens[k]; }
             t.sumsq = ws.sumsq + 6 * e;
             t.nonfinite = ws.nonfinite + e;
+            t.w_stride = pad_bias ? kBiasStride : 1;
+            t.drain_hot = use_hot ? 1 : 0;
             int tgrid = (int)((total / 4 + 255) / 256);
             if (tgrid > 512) tgrid = 512;
             if (tgrid < 1) tgrid = 1;
-            if (cfg->want_penalty) tail_kernel<true><<<dim3(tgrid), dim3(256), 0, stream>>>(t);
-            else tail_kernel<false><<<dim3(tgrid), dim3(256), 0, stream>>>(t);
+            if (cfg->want_penalty) {      // (the norms want the pending sums in the rows BEFORE they are read)
+                if (use_hot) hipLaunchKernelGGL(hot_reduce_kernel, dim3((n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 + 3) / 4), dim3(256), 0, stream, a);
+                tail_kernel<true><<<dim3(tgrid), dim3(256), 0, stream>>>(t, a);
+            } else tail_kernel<false><<<dim3(tgrid), dim3(256), 0, stream>>>(t, a);
         }
     }
-    if (vi_split) vi_split_kernel<false><<<dim3(vi_grid), dim3(256), 0, stream>>>((float4 *)b->v_i, (float4 *)ws.vi_split, cfg->n_items, vi_segs);
+    // A caller that keeps the engine layout (keep_layout) gets its weights back through rfm_fit_export_weights or a later call; everybody
+    // else now.  (After a failed epoch -- the verdict is only known behind the synchronisation below -- the layout is exported there.)
+    const bool keep = cfg->keep_layout && (pad_bias || vi_split) && epochs_launched == E;
+    if (!keep) export_layout();
     RFM_HIP(hipGetLastError());
 
     // ---- one synchronisation: bring the per-epoch results back
@@ -1140,7 +1190,14 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             epochs_done = e;
         }
     }
+    bool kept = keep;
+    if (keep && status != RFM_OK) {       // the reference has mutated its weights in place when it raises (rankfm/_rankfm.pyx:329): so has this call
+        export_layout();
+        RFM_HIP(hipStreamSynchronize(stream));
+        kept = false;
+    }
     if (rep) {
+        rep->layout_token = kept ? layout_kind : 0;
         for (int e = 0; e < E; ++e) {
             if (rep->log_likelihood) rep->log_likelihood[e] = h_ll[e];
             if (rep->n_draws) rep->n_draws[e] = (int64_t)h_draws[e];
@@ -1165,8 +1222,6 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         rep->working_groups = single_group ? 1 : ((max_groups > 0 && max_groups < row_groups) ? max_groups : row_groups);
         rep->units_per_launch = units_per_launch;
         rep->n_units = units;
-        rep->stripe_rows = stripe_rows;
-        rep->stripe_window = stripe_window;
         rep->segment_rows = use_segments ? seg_rows : 0;
         rep->table_producers = n_producers;
         rep->table_steps = (int64_t)h_err[2];

@@ -683,12 +683,17 @@ int rfm_recommend_device(const rfm_model_view *m, int64_t n_users, const float *
     // observed-item bits (4 bytes) and the users' effective factor rows.
     const int n_words = (m->n_items + kBlk - 1) / kBlk;
     if (n_rec <= kTopLocal && n_words <= kSegs && kp <= 512) {
-        // (12 n_words + 4 kp bytes per user out of 4 x 1024 x I: a chunk of at least 8 x 1024 users always fits)
-        const size_t per_user = 12 * (size_t)n_words + 4 * (size_t)kp + 16;
-        long long fchunk = (long long)(((size_t)chunk * I * sizeof(float)) / per_user);
+        // (3 n_words + kp floats per user out of 1024 x I: a chunk of at least 8 x 1024 users always fits.)  The three per-block arrays
+        // are each rounded up to 64 floats below, so 3 x 63 floats come off the budget FIRST: with a handful of users and a small
+        // catalogue the roundings are larger than the users' own share, and a chunk sized without them ran `mask` and `ueff_f` into
+        // `veff` (1 user x 42 - 192 items at kp = 32).  What does not fit takes the matrix path below.
+        const size_t per_user = 3 * (size_t)n_words + (size_t)kp;
+        const size_t area = (size_t)chunk * I, slack = 3 * 63;
+        long long fchunk = area > slack ? (long long)((area - slack) / per_user) : 0;
         fchunk = std::min<long long>(std::min<long long>(fchunk, kFusedChunk), n_users);
         if (fchunk >= 1 && (fchunk >= n_users || fchunk >= 64)) {
             if (fchunk < n_users) fchunk &= ~63LL;
+            if (3 * up256((size_t)n_words * fchunk) + (size_t)fchunk * kp > area) return RFM_ERR_WORKSPACE;      // (cannot happen: see `slack`)
             float *bmax_val = scores;
             int *bmax_idx = (int *)(bmax_val + up256((size_t)n_words * fchunk));
             unsigned *mask = (unsigned *)(bmax_idx + up256((size_t)n_words * fchunk));

@@ -13,16 +13,14 @@ namespace rfm {
 //   LDSF     the dense feature tables (v_uf, v_if, w_if) are read from this workgroup's LDS copy (see TMODE)
 //   HOT      updates of hot positive items are accumulated in the workgroup's LDS and published every few touches
 //   WARPB    compile the batched WARP draw loop (max_samples > 1); the BPR instantiation stays at ~76 VGPRs without it
-//   STRIPE   negatives come from the workgroup's LDS stripe: candidate rows are read from, and the negative's update is added
-//            to, LDS (snapshot + fixed-point pending delta); the user's item list is tested from registers when it is short
 //   TMODE    with LDSF: what the step updates (sgd_features_kernel).  0 = the rows only (v_u, v_i, w_i; the tables are a read-only
 //            copy), 1 = the tables only (the table trainer: plain read-modify-write on the master copy, groups of a wavefront one
 //            after the other), 2 = both (one group alone: the reference's sequential step)
-//   VISPLIT  the item factor rows are segment-major (SgdArgs::vi_split): full rows of 16-lane groups, no features, no stripes
+//   VISPLIT  the item factor rows are segment-major (SgdArgs::vi_split): full rows of 16-lane groups, no features
 template <int G, int KPL, bool SERIAL, bool FEAT, bool VU_REGS, bool FRESH, bool LDSF = false, bool HOT = false, bool WARPB = true,
-          bool STRIPE = false, int TMODE = 0, bool VISPLIT = false>
+          int TMODE = 0, bool VISPLIT = false>
 struct RowStep {
-    static_assert(!VISPLIT || (G == 16 && !FEAT && !STRIPE && !SERIAL), "segment-major item rows: the plain Hogwild row loops of 16-lane groups");
+    static_assert(!VISPLIT || (G == 16 && !FEAT && !SERIAL), "segment-major item rows: the plain Hogwild row loops of 16-lane groups");
     const SgdArgs &a;
     const int sub;                   // lane index inside the group
     const int F;
@@ -49,26 +47,6 @@ struct RowStep {
         return (float)__hip_atomic_exchange(p, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * kHotUnit;
     }
 
-    // negative stripe (STRIPE): [R] item of each row | [R, F+1] fp32 snapshot of v_i[item] and (last column) w_i[item] at window
-    // start | [R, F+1] pending updates in the same 32-bit fixed point as the hot sums.  A row's value is snapshot + pending.
-    lds_int *sn_item = nullptr;
-    lds_float *sn_snap = nullptr;
-    lds_int *sn_delta = nullptr;
-    // [F+1] column sums of sn_delta.  The positive item of a step sits, with probability stripe_cover, in some other
-    // workgroup's stripe and then carries pending pushes this workgroup cannot see; the workgroups run their windows in step
-    // and stripes are uniform samples of the items, so the MEAN pending sum of this workgroup's own stripe rows (x the cover)
-    // is what such an item is expected to carry.  Negative: published + own pending sum (exact, sequential inside the
-    // workgroup); positive: published + expected pending sum.  Without the correction every pairwise utility is
-    // overestimated by the positive's unseen downward pushes (log-likelihood -6 % against the sequential oracle at a 32-row
-    // window on config 2; with it +0.1 %, profiles/r02_notes.md).
-    // The BIAS column of the sums receives every push of the window with the same sign (about -eta * sample weight * d_outer each,
-    // groups x window of them: 2048 at 64 groups x 32 rows, 6144 with 4-lane groups), which would wrap the +-128-unit range of the
-    // pending sums; it is therefore kept in a unit kSumCoarse times coarser (range +-8192 x the step scale; the factor columns are
-    // sums of signed terms ~100 times smaller and keep the fine unit).
-    static constexpr float kSumCoarse = 64.0f;
-    lds_int *sn_sum = nullptr;
-    float sn_inv_rows = 0.0f;
-    int sn_rows = 0;
     // the user's sorted item list, held across the lanes when it has at most UL x G entries (lane s: entries s, s+G, ...; -1 pads):
     // the membership test of a draw is then UL compares and a ballot instead of a memory round trip
     // (WARP's state machine tests up to four candidates per iteration and its configurations have the long lists -- config 5's users hold
@@ -79,7 +57,7 @@ struct RowStep {
     //  whose segment-major instantiations are short of registers as it is -- keep 4 G.)
     //  Factor rows of at most 32 dwords (k <= 32: BASELINE config 1's k = 20, where MovieLens-like users hold 100 - 200 items) have the
     //  registers to spare for 16 G = 256 entries, BPR and WARP alike.
-    static constexpr int UL = (!FEAT && !STRIPE && !SERIAL && G == 16) ? (KPL <= 2 ? 16 : ((WARPB || KPL <= 4) ? 8 : 4)) : 4;
+    static constexpr int UL = (!FEAT && !SERIAL && G == 16) ? (KPL <= 2 ? 16 : ((WARPB || KPL <= 4) ? 8 : 4)) : 4;
     int32_t ulist[UL];
     bool ulist_ok = false;
     float user_scale = 1.0f;          // damping of this user's step (SgdArgs::user_cap), constant over a segment
@@ -112,59 +90,19 @@ struct RowStep {
             members4_group<G>(a.csr_items, lo, hi, c, m, sub);
         }
     }
-    // factor row + bias of item `it`.  An item of the workgroup's stripe (row `srow` >= 0) has two views:
-    //   screening (fresh = false): the snapshot taken when the window started -- an LDS read; WARP examines ~20 candidates per
-    //       update this way;
-    //   published (fresh = true): memory as of now (L1 bypassed) -- everything every workgroup has published, like the view
-    //       every step has of its POSITIVE item.  Used for the negative that is actually stepped.
-    // Both include the workgroup's own pending sum of the row.  The positive item's pending pushes sit unseen in some other
-    // workgroup's LDS, and a step that saw its negative's pending pushes but not its positive's would overestimate every
-    // pairwise utility (measured: log-likelihood -6 % against the sequential oracle at a 32-row window, profiles/r02_notes.md):
-    // the positive's view therefore carries the stripe's MEAN pending sum (sn_sum, operator()).  The alternatives that were
-    // measured (snapshot views, no own sums, biases published at once, reads through the atomic unit) are in the notes; the
-    // kernel compiles the chosen one only.
-    __device__ __forceinline__ void fetch_item(int32_t it, int srow, float (&v)[KPL], float &w, bool fresh = true) const {
-        if constexpr (STRIPE) {
-            if (srow >= 0) {
-                const int base = srow * (F + 1);
-                const float own = kHotUnit;
-                if (!fresh) {
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        v[k] = dword_ok(k) ? sn_snap[base + dword_f(k)] + (float)sn_delta[base + dword_f(k)] * own : 0.0f;
-                    w = sn_snap[base + F] + (float)sn_delta[base + F] * own;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k) v[k] = dword_ok(k) ? load_f32<true>(a.v_i + (size_t)it * F + dword_f(k)) : 0.0f;
-                    w = load_f32<true>(a.w_i + (size_t)it * a.w_stride);
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        if (dword_ok(k)) v[k] += (float)sn_delta[base + dword_f(k)] * own;
-                    w += (float)sn_delta[base + F] * own;
-                }
-                return;
-            }
-        }
+    // factor row + bias of item `it`
+    __device__ __forceinline__ void fetch_item(int32_t it, float (&v)[KPL], float &w) const {
         if constexpr (VISPLIT) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) v[k] = load_f32<FRESH>(a.v_i + vi_off(it, k));
         } else load_row<FRESH>(a.v_i + (size_t)it * F, v);
         w = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
     }
-    // raw draw -> candidate item (and its stripe row)
-    __device__ __forceinline__ int32_t draw_item(uint32_t raw, int &srow, uint32_t attempt) const {
-        if (STRIPE && sn_rows > 0 && attempt < RFM_STRIPE_ATTEMPTS) {
-            srow = (int)rfm_draw_to_item(raw, (uint32_t)sn_rows);
-            return sn_item[srow];
-        } else {
-            srow = -1;
-            return (int32_t)rfm_draw_to_item(raw, (uint32_t)a.n_items);
-        }
-    }
+    // raw draw -> candidate item
+    __device__ __forceinline__ int32_t draw_item(uint32_t raw) const { return (int32_t)rfm_draw_to_item(raw, (uint32_t)a.n_items); }
 
     __device__ __forceinline__ RowStep(const SgdArgs &args, int sub_, TabPtr v_uf, TabPtr v_if, TabPtr w_if)
-        : a(args), sub(sub_), F(STRIPE ? G * KPL : args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
-    // (stripe launches are planned for full factor rows only: the factor count is the compile-time constant G * KPL there)
+        : a(args), sub(sub_), F(args.n_factors), t_v_uf(v_uf), t_v_if(v_if), t_w_if(w_if) {}
 
     __device__ __forceinline__ int dword_f(int k) const { return sub + G * k; }
     // element index in `v_i` of this lane's dword k of item `it`
@@ -172,9 +110,7 @@ struct RowStep {
         if constexpr (VISPLIT) return ((size_t)k * (size_t)a.n_items + (size_t)it) * G + sub;
         else return (size_t)it * F + dword_f(k);
     }
-    // (stripe launches are planned for FULL factor rows only, F == G * KPL: no per-dword predicate -- a v_cmp, an exec-mask
-    //  save and a branch around every load, atomic and LDS update of the row loop otherwise)
-    __device__ __forceinline__ bool dword_ok(int k) const { return STRIPE || dword_f(k) < F; }
+    __device__ __forceinline__ bool dword_ok(int k) const { return dword_f(k) < F; }
 
     template <bool FR>
     __device__ __forceinline__ void load_row(const float *base, float (&r)[KPL]) const {
@@ -253,9 +189,8 @@ struct RowStep {
     //   w_i[it] + sum_q x_if[it,q] w_if[q] + sum_f [ (vu_f + A_f) * vi_f + B_f(it) * vu_f ]
     // A = x_uf[u] . v_uf  (user-feature projection), B(it) = x_if[it] . v_if  (item-feature projection)
     __device__ __forceinline__ float utility(const float (&vu)[KPL], const float (&A)[KPL], int32_t it, float (&vi)[KPL],
-                                             float (&B)[KPL], float &wi, int slot = -1, const XV *xit = nullptr, int srow = -1,
-                                             bool fresh = true) const {
-        fetch_item(it, srow, vi, wi, fresh);
+                                             float (&B)[KPL], float &wi, int slot = -1, const XV *xit = nullptr) const {
+        fetch_item(it, vi, wi);
         if constexpr (HOT) {
             if (slot >= 0) {      // the workgroup's own pending updates of a hot row are part of its view of the row
 #pragma unroll
@@ -285,9 +220,8 @@ struct RowStep {
     }
 
     // draw the next unobserved item for the user (rankfm/_rankfm.pyx:250-253)
-    __device__ __forceinline__ int32_t next_negative(int64_t lo, int64_t hi, uint32_t row_key, uint32_t &attempt, int &srow) const {
+    __device__ __forceinline__ int32_t next_negative(int64_t lo, int64_t hi, uint32_t row_key, uint32_t &attempt) const {
         int32_t j = 0;
-        srow = -1;
         if (SERIAL && a.rng == 0 /* RFM_RNG_MT19937 */) {
             if (sub == 0) {
                 do { j = (int32_t)(mt_next_global(a.mt_state) % (uint32_t)a.n_items); } while (is_member(a.csr_items, lo, hi, j));
@@ -295,7 +229,7 @@ struct RowStep {
             j = __shfl(j, (threadIdx.x & 63) - sub);
         } else {
             for (;;) {
-                j = draw_item(rfm_draw(row_key, attempt), srow, attempt);
+                j = draw_item(rfm_draw(row_key, attempt));
                 ++attempt;
                 if (!member(lo, hi, j)) break;
                 if (attempt >= kMaxAttempts) { if (sub == 0) atomicOr(a.error_flags, 1u); break; }
@@ -304,26 +238,9 @@ struct RowStep {
         return j;
     }
 
-    // the positive item's row, bias and step scale fetched ahead of the row's turn (segments kernel, STRIPE): rows of a segment
-    // depend on each other only through v_u, which lives in registers, so the next row's gathers overlap the current row
-    struct PosRow { float v[KPL]; float w, scale; };
-    __device__ __forceinline__ void prefetch_pos(int32_t it, PosRow &p) const {
-        load_row<FRESH>(a.v_i + (size_t)it * F, p.v);
-        if (STRIPE || a.scale_in_pad) {
-            // lanes 0 / 1 of the group read dwords 0 / 1 of the item's line: bias and step scale in ONE request
-            const float x = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride + (sub & 1));
-            const int base = (threadIdx.x & 63) - sub;
-            p.w = __shfl(x, base);
-            p.scale = __shfl(x, base + 1);
-        } else {
-            p.w = load_f32<FRESH>(a.w_i + (size_t)it * a.w_stride);
-            p.scale = a.pos_scale ? a.pos_scale[it] : 1.0f;
-        }
-    }
-
     // `vu` holds v_u[u] on entry; with VU_REGS it holds the updated row on exit
     __device__ __forceinline__ void operator()(uint32_t row_key, int32_t u, int32_t i, float sw, int64_t lo, int64_t hi,
-                                               float (&vu)[KPL], double &ll_acc, unsigned &draw_acc, const PosRow *pre = nullptr) const {
+                                               float (&vu)[KPL], double &ll_acc, unsigned &draw_acc) const {
         uint32_t attempt = 0;
         float A[KPL];
         XV xu, xi, xj, xc;
@@ -336,9 +253,8 @@ struct RowStep {
         int slot = -1;
         float pos_scale_i = 1.0f;
         if constexpr (!SERIAL) {
-            if (STRIPE || a.pos_scale) {
-                // (stripe launches always carry bias and step scale in the item's padded line: scale 1 when nothing is damped)
-                pos_scale_i = (STRIPE || pre) ? pre->scale : a.pos_scale[i];
+            if (a.pos_scale) {
+                pos_scale_i = a.pos_scale[i];
                 // a hot item's entry carries its accumulator slot above the scale (SgdArgs::hot_item).  EVERY instantiation decodes
                 // it: the plan of a launch is shared by kernels with and without accumulators (the step producers of the features
                 // kernel score hot items through this generic step -- undecoded, their staged steps were up to ~130 x too long)
@@ -353,7 +269,6 @@ struct RowStep {
         float vj[KPL], Bj[KPL], wj = 0.0f;
         float min_pu = 1e6f;
         int32_t j = -1;
-        int jrow = -1;                // stripe row of the chosen negative (STRIPE)
         int sampled = 0;
         float ut_ui = 0.0f;
         int s = 1;
@@ -366,8 +281,7 @@ struct RowStep {
         // (the reference's ut_ui - ut_uj, :239 and :256-257, regrouped; Bi then holds B(i) - B(j) and Bj zero)
         constexpr bool BPRF = FEAT && LDSF && !WARPB;
         if constexpr (BPRF) {
-            int srow_unused;
-            j = next_negative(lo, hi, row_key, attempt, srow_unused);
+            j = next_negative(lo, hi, row_key, attempt);
             sampled = 1;
             load_row<FRESH>(a.v_i + (size_t)i * F, vi);
             load_row<FRESH>(a.v_i + (size_t)j * F, vj);
@@ -402,46 +316,19 @@ struct RowStep {
             for (int k = 0; k < KPL; ++k) part += (vu[k] + A[k]) * (vi[k] - vj[k]) + Bi[k] * vu[k];
             min_pu = (wi - wj) + scalar + group_sum<G>(part);
         } else {
-        if (STRIPE && pre) {
-            // (STRIPE has no features: the utility is bias + dot product, on the prefetched row)
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) vi[k] = pre->v[k];
-            wi = pre->w;
-            if constexpr (HOT) {
-                if (slot >= 0) {
-#pragma unroll
-                    for (int k = 0; k < KPL; ++k)
-                        if (dword_ok(k)) vi[k] += (float)hot_acc[slot * F + dword_f(k)] * kHotUnit;
-                    wi += (float)hot_accw[slot] * kHotUnit;
-                }
-            }
-            if (sn_rows > 0) {
-                const float c = kHotUnit * sn_inv_rows;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k)
-                    if (dword_ok(k)) vi[k] += (float)sn_sum[dword_f(k)] * c;
-                wi += (float)sn_sum[F] * (c * kSumCoarse);
-            }
-            float part = 0.0f;
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) part += vu[k] * vi[k];
-            ut_ui = wi + group_sum<G>(part);
-        } else
         ut_ui = utility(vu, A, i, vi, Bi, wi, slot, &xi);    // :239
 
         // WARP sampling loop (:244-264); BPR is max_samples == 1
         // first draw (all of BPR): one candidate at a time
         for (; s <= ((BATCH_WARP || (!SERIAL && !FEAT && !WARPB)) ? 1 : a.max_samples); ++s) {
-            int crow;
-            const int32_t cand = next_negative(lo, hi, row_key, attempt, crow);
+            const int32_t cand = next_negative(lo, hi, row_key, attempt);
             float vc[KPL], Bc[KPL], wc;
             if constexpr (FEAT) { if (a.has_if) xload(a.x_if + (size_t)cand * a.n_if, a.n_if, xc); }
-            // (stripes: BPR steps its one candidate -> exact view; WARP screens candidates on the snapshot)
-            const float pu = ut_ui - utility(vu, A, cand, vc, Bc, wc, -1, &xc, crow, !(STRIPE && WARPB));   // :256-257
+            const float pu = ut_ui - utility(vu, A, cand, vc, Bc, wc, -1, &xc);   // :256-257
             sampled = s;
             if (pu < min_pu || j < 0) {                                   // :259-261 (j < 0: keep a valid index under NaN)
                 if (pu < min_pu) min_pu = pu;
-                j = cand; wj = wc; jrow = crow;
+                j = cand; wj = wc;
                 if constexpr (FEAT) xj = xc;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) { vj[k] = vc[k]; if constexpr (FEAT) Bj[k] = Bc[k]; }
@@ -456,10 +343,9 @@ struct RowStep {
             s = 2;
             while (!done && s <= a.max_samples) {
                 int32_t c[4];
-                int crow[4];
                 bool mem[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) c[q] = draw_item(rfm_draw(row_key, attempt + q), crow[q], attempt + q);
+                for (int q = 0; q < 4; ++q) c[q] = draw_item(rfm_draw(row_key, attempt + q));
                 attempt += 4;
                 members4(lo, hi, c, mem);
                 // rows are fetched NB at a time: four at KPL <= 6; two at KPL >= 8, where four rows of registers spill and two
@@ -473,7 +359,7 @@ struct RowStep {
                     for (int q = 0; q < NB; ++q) {
                         part[q] = 0.0f;
                         wc[q] = 0.0f;
-                        if (!mem[q0 + q]) fetch_item(c[q0 + q], crow[q0 + q], vc[q], wc[q], false);
+                        if (!mem[q0 + q]) fetch_item(c[q0 + q], vc[q], wc[q]);
                     }
 #pragma unroll
                     for (int q = 0; q < NB; ++q)
@@ -490,7 +376,7 @@ struct RowStep {
                         sampled = s;
                         ++s;
                         if (pu < min_pu) {
-                            min_pu = pu; j = c[q0 + q]; wj = wc[q]; jrow = crow[q0 + q];
+                            min_pu = pu; j = c[q0 + q]; wj = wc[q];
 #pragma unroll
                             for (int k = 0; k < KPL; ++k) vj[k] = vc[q][k];
                         }
@@ -498,16 +384,6 @@ struct RowStep {
                     }
                 }
                 if (attempt >= kMaxAttempts) { if (sub == 0) atomicOr(a.error_flags, 1u); break; }
-            }
-        }
-        if constexpr (STRIPE && WARPB) {
-            // the negative that was chosen on the snapshot is stepped on its exact view: row, bias and pairwise utility again
-            if (jrow >= 0) {
-                fetch_item(j, jrow, vj, wj, true);
-                float part = 0.0f;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) part += vu[k] * vj[k];
-                min_pu = ut_ui - (wj + group_sum<G>(part));
             }
         }
         const float pu = min_pu;                                          // :267-268
@@ -518,8 +394,8 @@ struct RowStep {
         // profiles/r04_notes.md.)  Same line as the bias just read (padded table) or the plan's scale array.
         float neg_scale_j = 1.0f;
         if constexpr (!SERIAL) {
-            if (STRIPE || a.pos_scale) {
-                float sc = (STRIPE || a.scale_in_pad) ? a.w_i[(size_t)j * a.w_stride + 1] : a.pos_scale[j];
+            if (a.pos_scale) {
+                float sc = a.scale_in_pad ? a.w_i[(size_t)j * a.w_stride + 1] : a.pos_scale[j];
                 if (sc >= 2.0f) sc -= 2.0f * floorf(sc * 0.5f);           // (a hot item's entry carries its slot above the scale)
                 neg_scale_j = sc;
             }
@@ -533,69 +409,18 @@ struct RowStep {
         float eta_u = eta, eta_i = eta, eta_f = eta;
         const float eta_j = a.damp_positive_only ? eta : eta * neg_scale_j;
         if constexpr (!SERIAL) {
-            if constexpr (STRIPE) eta_u = eta * user_scale;          // (per segment: load_ulist)
-            else eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
+            eta_u = eta * fminf(1.0f, a.user_cap / (float)(hi - lo));
             eta_i = eta * pos_scale_i;
             if constexpr (!LDSF) eta_f = eta * a.feat_scale;
         }
         float nvu[KPL], dij[KPL];     // updated v_u, updated (v_i - v_j) (feature paths)
-        if constexpr (STRIPE && !SERIAL && !FEAT && VU_REGS) {
-            // The same arithmetic as the generic code below, arranged for the stripe instantiations: every delta first, then ONE
-            // branch per publication target (hot slot or atomics for the positive, stripe row or atomics for the negative)
-            // instead of one per dword.
-            float d_i[KPL], d_j[KPL];
-#pragma unroll
-            for (int k = 0; k < KPL; ++k) {
-                const float g_u = vi[k] - vj[k];                                     // :292
-                const float g_i = vu[k];                                             // :293-294 (d_v_j = -d_v_i)
-                const float d_u = eta_u * (g * (d_outer * g_u) - reg_a * vu[k]);     // :308
-                d_i[k] = eta_i * (g * (d_outer * g_i) - reg_a * vi[k]);              // :309
-                d_j[k] = eta_j * (g * (d_outer * -g_i) - reg_a * vj[k]);             // :310
-                vu[k] += d_u;
-            }
-            const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);           // :279
-            const float dwj = eta_j * (g * (d_outer * -1.0f) - reg_a * wj);         // :280
-            if (HOT && slot >= 0) {
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) hot_add(hot_acc + slot * F + dword_f(k), d_i[k]);
-                if (sub == 0) hot_add(hot_accw + slot, dwi);
-            } else {
-                float *pv = a.v_i + (size_t)i * F + sub;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) atomic_add_f32(pv + G * k, d_i[k]);
-                if (sub == 0) atomic_add_f32(a.w_i + (size_t)i * a.w_stride, dwi);
-            }
-            if (jrow >= 0) {
-                lds_int *pd = sn_delta + jrow * (F + 1) + sub, *ps = sn_sum + sub;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) {
-                    const int q = __float2int_rn(d_j[k] * kHotScale);
-                    __hip_atomic_fetch_add(pd + G * k, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(ps + G * k, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                if (sub == 0) {
-                    const int q = __float2int_rn(dwj * kHotScale);
-                    __hip_atomic_fetch_add(sn_delta + jrow * (F + 1) + F, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(sn_sum + F, __float2int_rn(dwj * (kHotScale * (1.0f / kSumCoarse))), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            } else {
-                float *pv = a.v_i + (size_t)j * F + sub;
-#pragma unroll
-                for (int k = 0; k < KPL; ++k) atomic_add_f32(pv + G * k, d_j[k]);
-                if (sub == 0) atomic_add_f32(a.w_i + (size_t)j * a.w_stride, dwj);
-            }
-        } else {
         // item biases (:279-280) -- one lane per group
         if (UPD_ROWS && sub == 0) {
             const float dwi = eta_i * (g * (d_outer * 1.0f) - reg_a * wi);
             const float dwj = eta_j * (g * (d_outer * -1.0f) - reg_a * wj);
             if (HOT && slot >= 0) hot_add(hot_accw + slot, dwi);
             else apply_f32<SERIAL>(a.w_i + (size_t)i * a.w_stride, wi, dwi);
-            if (STRIPE && jrow >= 0) {
-                hot_add(sn_delta + jrow * (F + 1) + F, dwj);
-                hot_add(sn_sum + F, dwj * (1.0f / kSumCoarse));
-            } else apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj);
+            apply_f32<SERIAL>(a.w_i + (size_t)j * a.w_stride, wj, dwj);
         }
 
         // factor updates (:289-326), this lane's dwords
@@ -614,21 +439,19 @@ struct RowStep {
                 if constexpr (!VU_REGS) apply_f32<SERIAL>(a.v_u + (size_t)u * F + f, vu[k], d_u);
                 if (HOT && slot >= 0) hot_add(hot_acc + slot * F + f, d_i);
                 else apply_f32<SERIAL>(a.v_i + vi_off(i, k), vi[k], d_i);
-                if (STRIPE && jrow >= 0) { hot_add(sn_delta + jrow * (F + 1) + f, d_j); hot_add(sn_sum + f, d_j); }
-                else apply_f32<SERIAL>(a.v_i + vi_off(j, k), vj[k], d_j);
+                apply_f32<SERIAL>(a.v_i + vi_off(j, k), vj[k], d_j);
             }
         }
         if constexpr (VU_REGS && UPD_ROWS) {
 #pragma unroll
             for (int k = 0; k < KPL; ++k) vu[k] = nvu[k];
         }
-        }
         if constexpr (HOT) {
             if (slot >= 0) {
                 // every hot_period-th toucher of the slot publishes what the workgroup has accumulated for it
                 // (a keyed coin with probability 1 / period instead of a shared counter: no LDS round trip on the row's path)
                 if (__umulhi(rfm_mix32(row_key ^ 0x7A5C3B1DU), (uint32_t)a.hot_period[slot]) == 0u) {     // probability 1 / period
-                    RFM_COLD_ARGS(c, !STRIPE)
+                    RFM_COLD_ARGS(c)
 #pragma unroll
                     for (int k = 0; k < KPL; ++k) {
                         if (!dword_ok(k)) continue;

@@ -61,25 +61,21 @@ struct SgdArgs {
     // workgroups publishing into the same 64 rows cost 0.55 ms of a 3.6 ms epoch (measured by publishing to private
     // addresses instead).  A workgroup adds its pending sums into bin (workgroup % kHotBins) of these arrays; every
     // 64-byte line of the bins has an owner workgroup that sweeps it every few rows (exchange with zero over the bins,
-    // one atomic add of the total into v_i / w_i), and hot_reduce_kernel drains what is left when the launch ends.
+    // one atomic add of the total into v_i / w_i); what is left when a launch ends is drained by the epoch tail or the export (rfm_api.hip).
     // With few workgroups (fewer than a quarter of the lines) there is little contention and a sweeping turn would take
     // long: hot_direct = 1 publishes straight into the rows.
     float *hot_bins_v;                          // [kHotBins, n_hot, F]   (hot_bin_v)
     float *hot_bins_w;                          // [kHotBins, n_hot]      (hot_bin_w)
     int32_t hot_direct;
     const unsigned int *sw_max_bits;            // bits of max |sample_weight| (plan): range of the fixed-point hot sums
-    // negative stripes (segments kernel, STRIPE instantiation; include/rfm_rng.h "negative stripes"): the workgroup draws the
-    // negatives of a window of `stripe_window` rows per group from `stripe_rows` items whose rows it holds in LDS
-    int32_t stripe_rows, stripe_window;
-    uint32_t item_bits, launch_index;
-    float stripe_cover;                         // share of the catalogue that sits in some workgroup's stripe at any time, <= 1
+    uint32_t launch_index;                      // which launch of the epoch this is (keys the step producers' row sample)
     // features kernel: the step producers hand their batches to the table trainer through `feat_ring` ([2 * n_producers] slots of
     // one staged step per row group of a workgroup), synchronised by the counters in `feat_flags` (sgd_features_kernel)
     float *feat_ring;
     unsigned int *feat_flags;
     int32_t n_producers;
     int32_t feat_frozen;                        // debug: the feature tables are not trained (no trainer, no producers)
-    // dynamic segment order (segments kernel without stripes, pipelined feature row loop): a row group takes its next segment from
+    // dynamic segment order (segments kernel, WARP kernel, pipelined feature row loop): a row group takes its next segment from
     // a ticket counter instead of striding the order with the number of groups (SegmentTickets below); nullptr = static stride
     unsigned int *tickets;                      // the launch's counter of order positions handed out, zero at launch
     int32_t damp_positive_only;                 // experiments: the round-3 rule (an item's scale applies to its step as the POSITIVE item only)
@@ -112,8 +108,6 @@ constexpr int kTicketWords = 16;                // one counter per launch, on a 
 constexpr int kHotBins = 16;
 
 constexpr size_t kLdsBytes = 160 * 1024;        // per workgroup on gfx950
-// LDS floats of a negative stripe of R rows: [R] items | [R, F+1] snapshot | [R, F+1] pending sums | [F+1] their column sums
-inline size_t stripe_lds_floats(int rows, int n_factors) { return (size_t)rows * (1 + 2 * ((size_t)n_factors + 1)) + (size_t)n_factors + 1; }
 
 constexpr float kMargin = 1.0f;                 // rankfm/_rankfm.pyx:149
 constexpr uint32_t kMaxAttempts = 1u << 22;     // safety net; the host rejects saturated users up front
@@ -151,10 +145,7 @@ __device__ __forceinline__ SgdArgs cold_args() {
     return SgdArgs();                  // (the host pass of the compiler only parses device code)
 #endif
 }
-// (the frozen stripe instantiations keep the code they were measured with: with COLD = false, `c` IS the kernel's parameter)
-#define RFM_COLD_ARGS(c, COLD)                                            \
-    const SgdArgs c##_reread_ = (COLD) ? cold_args() : SgdArgs();         \
-    const SgdArgs &c = (COLD) ? c##_reread_ : a;
+#define RFM_COLD_ARGS(c) const SgdArgs c = cold_args();
 
 template <int G>
 __device__ __forceinline__ float group_sum(float x) {
@@ -427,8 +418,7 @@ static __global__ void __launch_bounds__(256) hot_reduce_kernel(const SgdArgs a)
 }
 
 // host-side launcher table (rfm_sgd_inst_*.hip): [0..3] rows kernel {hogwild, hogwild+feat, serial, serial+feat},
-// [4..7] segments kernel {plain, features kernel, fresh, features kernel fresh}, [8..9] segments kernel with hot-row accumulators {plain, fresh},
-// [10..13] segments kernel with negative stripes {plain, fresh, hot, hot+fresh}
+// [4..7] segments kernel {plain, features kernel, fresh, features kernel fresh}, [8..9] segments kernel with hot-row accumulators {plain, fresh}
 typedef void (*sgd_launch_fn)(const SgdArgs &, int grid, hipStream_t);
 
 // second stream of the features path (rfm_api.hip): the tables kernel forks off the caller's stream and joins it again

@@ -352,7 +352,7 @@ __device__ __forceinline__ void feat_step_producer(const SgdArgs &a, lds_float *
     lds_float *stage = lds + n_tab;
     __syncthreads();
     // ---- a step producer ----------------------------------------------------------------------------------------------------
-    typedef RowStep<G, KPL, false, true, true, true, true, false, WARPB, false, 1> Train;
+    typedef RowStep<G, KPL, false, true, true, true, true, false, WARPB, 1> Train;
     Train step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     const int p = (int)blockIdx.x - 1;
     double ll_unused = 0.0;
@@ -439,8 +439,8 @@ __device__ __forceinline__ void feat_generic_rows(const SgdArgs &a, lds_float *l
     if (threadIdx.x == 0 && blockIdx.x == 0) a.feat_clock[2] = wall_clock64();
     for (int k = threadIdx.x; k < n_tab; k += blockDim.x) lds_tables[k] = *table_ptr(k);
     __syncthreads();
-    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 0> Reg;
-    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, false, 2> Both;
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, 0> Reg;
+    typedef RowStep<G, KPL, false, true, true, FRESH, true, false, WARPB, 2> Both;
     Reg step(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     Both both(a, sub, lds, lds + n_uf_f, lds + n_uf_f + n_if_f);
     const bool train_here = a.single_group && !a.feat_frozen;          // one group alone trains the tables in its LDS
@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
             hot_unit = range / 16777216.0f;
         }
         __syncthreads();
-        typedef RowStep<G, KPL, false, true, true, FRESH, true, false, false, false, 0> Reg;
+        typedef RowStep<G, KPL, false, true, true, FRESH, true, false, false, 0> Reg;
         Reg step(a, sub, lds, lds, lds);                               // (draws, membership test, user damping; its tables are unused)
         const lds_float *uf_lane = t_uf + sub * KPL, *if_lane = t_if + sub * KPL;
         const int lane_base = lane - sub;
@@ -701,8 +701,7 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
                 }
                 // the negative (:250-253) and its gathers
                 uint32_t attempt = 0;
-                int srow_unused;
-                const int32_t j = step.next_negative(lo, hi, row_key, attempt, srow_unused);
+                const int32_t j = step.next_negative(lo, hi, row_key, attempt);
                 float vj[KPL], wj, xj0 = 0.0f, xj1 = 0.0f;
 #pragma unroll
                 for (int k = 0; k < KPL; ++k) vj[k] = (sub + G * k < F) ? load_f32<FRESH>(a.v_i + (size_t)j * F + sub + G * k) : 0.0f;

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
     auto vi_at = [&](int32_t item, int k) { return a.v_i + (size_t)item * F + sub + G * k; };      // (row-major: see rfm_api.hip, vi_split_eligible)
     extern __shared__ __attribute__((aligned(16))) float lds_tables[];
     lds_float *lds = (lds_float *)lds_tables;
-    typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, true, false> Step;       // draws, membership test, fixed-point hot sums
+    typedef RowStep<G, KPL, false, false, true, FRESH, false, HOT, true> Step;       // draws, membership test, fixed-point hot sums
     Step step(a, sub, a.v_uf, a.v_if, a.w_if);
     // LDS: [n_hot * F] pending factor deltas | [n_hot] pending bias deltas | [n_hot] (unused) -- like the HOT segments kernel -- then
     // the WARP multipliers (:269) and the hot slots' publication periods, read on every update
@@ -217,8 +217,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_warp_kernel(const SgdArg
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
                 if (q == 0 && starts) { c[0] = i; skip[0] = false; continue; }
-                int srow_unused;
-                c[q] = step.draw_item(rfm_draw(row_key, attempt), srow_unused, attempt);
+                c[q] = step.draw_item(rfm_draw(row_key, attempt));
                 ++attempt;
                 skip[q] = step.member(lo, hi, c[q]);      // (rankfm/_rankfm.pyx:250-253: a drawn item of the user's own is drawn again)
             }

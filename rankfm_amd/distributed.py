@@ -854,7 +854,7 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
                                             syncs_per_epoch=syncs_per_epoch, overlap=overlap if merge_damping is None else False, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
                                             want_penalty=verbose, hogwild_damping=model.engine.damping,
                                             # every engine option of the single-GPU path applies to the shards as well
-                                            debug_flags=int(model.engine.debug_flags), negative_stripes=model.engine.negative_stripes,
+                                            debug_flags=int(model.engine.debug_flags),
                                             tune=model.engine.tune, n_workgroups=model.engine.n_workgroups,
                                             rows_per_launch=model.engine.rows_per_launch, check_finite=model.engine.check_finite)
         finish = (lambda: sess.weights["v_u"].detach().cpu().numpy()) if sess is not None else (lambda: np.zeros((0, model.factors), np.float32))   # noqa: E731

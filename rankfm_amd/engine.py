@@ -19,7 +19,7 @@ class DeviceSession:
                  learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25, max_samples=1,
                  mode="hogwild", rng="counter", seed=1492, device=None, n_workgroups=0, rows_per_launch=0,
                  check_finite=True, want_penalty=False, has_user_features=None, has_item_features=None,
-                 shape_override=0, hogwild_damping=0.0, debug_flags=0, tune=None, negative_stripes=False):
+                 shape_override=0, hogwild_damping=0.0, debug_flags=0, tune=None, keep_layout=False):
         if not torch.cuda.is_available():
             raise _hip.EngineUnavailable("no MI355X visible to PyTorch-ROCm: rankfm_amd has no CPU fallback")
         _hip.lib()
@@ -64,22 +64,61 @@ class DeviceSession:
         self.hogwild_damping = float(hogwild_damping)
         self._plan_token = 0
         self.debug_flags = int(debug_flags)
-        self.sampler = _hip.SAMPLER_STRIPES if negative_stripes else _hip.SAMPLER_UNIFORM      # (see EngineOptions.negative_stripes)
-        self.tune = _hip.tune_kwargs(tune)       # geometry overrides (experiments); part of the plan, so fixed per session
+        # the experiments' overrides (rfm_fit_tuning): part of the plan, so fixed per session; None = production (a NULL pointer)
+        self._tuning = _hip.make_tuning(tune, n_workgroups=self.n_workgroups, rows_per_launch=self.rows_per_launch,
+                                        debug_shape=self.shape_override, debug_flags=self.debug_flags)
         self._geometry = None
+        # keep_layout: between `run` calls the item-side weights stay in the engine's working layout inside the workspace (segment-major
+        # factor rows, padded biases: rfm_fit_config.keep_layout) -- `self.weights["v_i"]` / `["w_i"]` are then STALE until `sync_weights()`
+        # (which `weights_to_host`, `predict` and `recommend` call).  For a resident single-GPU training loop; callers that touch the
+        # weight tensors between runs themselves (the multi-GPU exchange works on them) leave it off.
+        self.keep_layout = bool(keep_layout)
+        self._layout_token = 0
+        self._layout_cfg = None
 
     def _config(self, epochs, epoch_begin, part=None, rng_epoch_offset=0):
-        return _hip.FitConfig(
+        cfg = _hip.FitConfig(
             rng_epoch_offset=int(rng_epoch_offset),
             epoch_part_index=part[0] if part else 0, epoch_parts=part[1] if part else 0,
-            hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token), debug_flags=self.debug_flags, sampler=self.sampler,
-            debug_update_mode=0, debug_shape=self.shape_override,
+            hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token),
+            keep_layout=int(self.keep_layout), layout_token=int(self._layout_token),
             n_interactions=self.n_interactions, n_users=self.n_users, n_items=self.n_items,
             n_user_features=self.n_user_features, n_item_features=self.n_item_features, n_factors=self.n_factors,
             has_user_features=self.has_uf, has_item_features=self.has_if,
             epochs=int(epochs), epoch_begin=int(epoch_begin), mode=self.mode, rng=self.rng, seed=self.seed,
-            check_finite=self.check_finite, want_penalty=self.want_penalty,
-            n_workgroups=self.n_workgroups, rows_per_launch=self.rows_per_launch, **self.tune, **self.hyper)
+            check_finite=self.check_finite, want_penalty=self.want_penalty, **self.hyper)
+        if self._tuning is not None:
+            cfg.tuning = C.pointer(self._tuning)
+        return cfg
+
+    def _buffers(self, perms_t=None):
+        w = self.weights
+        return _hip.FitBuffers(
+            interactions=self.interactions.data_ptr(), sample_weight=self.sample_weight.data_ptr(),
+            csr_offsets=self.csr_offsets.data_ptr(), csr_items=self.csr_items.data_ptr(),
+            x_uf=self.x_uf.data_ptr(), x_if=self.x_if.data_ptr(),
+            w_i=w["w_i"].data_ptr(), w_if=w["w_if"].data_ptr(), v_u=w["v_u"].data_ptr(), v_i=w["v_i"].data_ptr(),
+            v_uf=w["v_uf"].data_ptr(), v_if=w["v_if"].data_ptr(),
+            perms=perms_t.data_ptr() if perms_t is not None else None,
+            workspace=self._workspace.data_ptr(), workspace_bytes=self._workspace.numel())
+
+    def sync_weights(self):
+        """with `keep_layout`: bring `self.weights["v_i"]` / `["w_i"]` up to date from the engine's working layout in the workspace
+        (rfm_fit_export_weights; enqueued on the current stream, no host synchronisation).  The workspace stays current: training goes on
+        from it.  A no-op when nothing was kept."""
+        if not self._layout_token:
+            return
+        cfg = self._layout_cfg
+        cfg.plan_token, cfg.layout_token = int(self._plan_token), int(self._layout_token)
+        buf = self._buffers()
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _hip.raise_for_status(_hip.lib().rfm_fit_export_weights(C.byref(cfg), C.byref(buf), C.c_void_p(stream)))
+
+    def invalidate_layout(self):
+        """the caller has written `self.weights["v_i"]` / `["w_i"]` itself: export what the engine holds first (`sync_weights`), then call
+        this so that the next run imports the tensors again"""
+        self._layout_token = 0
 
     def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True, part=None, rng_epoch_offset=0):
         """train `epochs` epochs in place on the resident tensors; returns the per-epoch report (numpy arrays)"""
@@ -88,22 +127,18 @@ class DeviceSession:
         if need == 0:
             _hip.raise_for_status(_hip.lib().rfm_fit_supported(C.byref(cfg)))
         if self._workspace is None or self._workspace.numel() < need:
+            self.sync_weights()                  # (a kept layout lives in the workspace that is about to be replaced)
             self._workspace = torch.empty(int(need), dtype=torch.uint8, device=self.device)
-            self._plan_token = 0
-            cfg.plan_token = 0
+            self._plan_token = self._layout_token = 0
+            cfg.plan_token = cfg.layout_token = 0
+        if perms is not None and self._layout_token:
+            self.sync_weights()                  # (explicit orders run another kernel on another plan: back to the caller's layout first)
+            self._layout_token = cfg.layout_token = 0
         perms_t = None
         if perms is not None:
             perms_t = torch.as_tensor(np.ascontiguousarray(perms, dtype=np.int32)).to(self.device)
             assert tuple(perms_t.shape) == (epochs, self.n_interactions)
-        w = self.weights
-        buf = _hip.FitBuffers(
-            interactions=self.interactions.data_ptr(), sample_weight=self.sample_weight.data_ptr(),
-            csr_offsets=self.csr_offsets.data_ptr(), csr_items=self.csr_items.data_ptr(),
-            x_uf=self.x_uf.data_ptr(), x_if=self.x_if.data_ptr(),
-            w_i=w["w_i"].data_ptr(), w_if=w["w_if"].data_ptr(), v_u=w["v_u"].data_ptr(), v_i=w["v_i"].data_ptr(),
-            v_uf=w["v_uf"].data_ptr(), v_if=w["v_if"].data_ptr(),
-            perms=perms_t.data_ptr() if perms_t is not None else None,
-            workspace=self._workspace.data_ptr(), workspace_bytes=self._workspace.numel())
+        buf = self._buffers(perms_t)
         ll = np.zeros(epochs, dtype=np.float64)
         pen = np.zeros(epochs, dtype=np.float64)
         ms = np.zeros(epochs, dtype=np.float32)
@@ -114,7 +149,12 @@ class DeviceSession:
         with torch.cuda.device(self.device):
             stream = torch.cuda.current_stream(self.device).cuda_stream
             rc = _hip.lib().rfm_fit_device(C.byref(cfg), C.byref(buf), C.c_void_p(stream), C.byref(rep))
-        self._plan_token = int(rep.plan_token) if (rc == _hip.OK and perms is None) else 0
+        if rc in (_hip.ERR_BAD_ARG, _hip.ERR_UNKNOWN_SCHEDULE, _hip.ERR_UNSUPPORTED, _hip.ERR_WORKSPACE, _hip.ERR_NO_DEVICE):
+            pass                                 # (refused before anything ran: plan and layout in the workspace are what they were)
+        else:
+            self._plan_token = int(rep.plan_token) if (rc == _hip.OK and perms is None) else 0
+            self._layout_token = int(rep.layout_token) if self._plan_token else 0
+            self._layout_cfg = cfg if self._layout_token else None
         self._geometry = dict(rep.geometry(), single_group=bool(self.debug_flags & 1), seed=self.seed,
                               epoch_part=part)
         out = dict(status=rc, log_likelihood=ll, reg_penalty=pen, sgd_kernel_ms=ms, n_draws=draws,
@@ -147,11 +187,13 @@ class DeviceSession:
         return pos, np.minimum(1.0, user_cap / deg).astype(np.float32)
 
     def weights_to_host(self):
+        self.sync_weights()
         return {k: v.detach().cpu().numpy() for k, v in self.weights.items()}
 
     # ---- serving on the resident model: `_predict` / `_recommend` (rankfm/_rankfm.pyx:345-390, 393-460) without the uploads of the
     #      host entry points -- the model, the feature matrices and the users' item lists are already in HBM --------------------------------
     def _model_view(self):
+        self.sync_weights()
         w = self.weights
         return _hip.ModelView(
             n_users=self.n_users, n_items=self.n_items, n_user_features=self.n_user_features, n_item_features=self.n_item_features,

@@ -41,23 +41,3 @@ def c2_problem():
     U, I, N, F = cfg["n_users"], cfg["n_items"], cfg["n_interactions"], cfg["factors"]
     pairs, csr = synthetic.make_interactions(U, I, N, seed=0)
     return U, I, N, F, pairs, csr
-
-
-def stripes_built():
-    """True only for a library built with RFM_STRIPES=1 (rankfm_amd/_build.py): the default build leaves the frozen opt-in stripe sampler out"""
-    from rankfm_amd import _hip
-    cfg = _hip.FitConfig(n_interactions=1, n_users=1, n_items=2, n_user_features=1, n_item_features=1, n_factors=16, max_samples=1, epochs=1,
-                         mode=_hip.MODE_HOGWILD, rng=_hip.RNG_COUNTER, sampler=_hip.SAMPLER_STRIPES)
-    import ctypes as C
-    return _hip.lib().rfm_fit_supported(C.byref(cfg)) == _hip.OK
-
-
-@pytest.fixture(autouse=True)
-def _stripe_tests_need_the_stripe_kernels(request):
-    """GPU tests of the opt-in stripe sampler skip when the library was built without it"""
-    if "gpu" not in request.keywords:
-        return
-    params = getattr(getattr(request.node, "callspec", None), "params", {})
-    about_stripes = "stripe" in request.node.name.lower() or params.get("stripes") is True or params.get("sampler") == "stripes"
-    if about_stripes and not stripes_built():
-        pytest.skip("librankfm_hip.so was built without the opt-in stripe sampler (the default; RFM_STRIPES=1 builds it in)")

@@ -35,8 +35,8 @@ def test_exports_every_declared_symbol(lib):
 
 def test_struct_layouts_match_the_header(tmp_path):
     """compile the header with gcc and compare sizeof/offsetof with the ctypes mirror"""
-    structs = {"rfm_fit_config": _hip.FitConfig, "rfm_fit_buffers": _hip.FitBuffers, "rfm_fit_report": _hip.FitReport,
-               "rfm_model_view": _hip.ModelView}
+    structs = {"rfm_fit_config": _hip.FitConfig, "rfm_fit_tuning": _hip.FitTuning, "rfm_fit_buffers": _hip.FitBuffers,
+               "rfm_fit_report": _hip.FitReport, "rfm_model_view": _hip.ModelView}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rankfm_hip.h"', 'int main(void){']
     for cname, ct in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -133,12 +133,31 @@ def test_the_library_reads_no_environment_variable():
 
 
 def test_geometry_overrides_are_validated(lib):
-    cfg = _hip.FitConfig(n_interactions=10, n_users=4, n_items=5, n_user_features=1, n_item_features=1, n_factors=8, max_samples=1,
-                         epochs=1, learning_schedule=0, mode=0, rng=1)
+    """the experiments' overrides live in rfm_fit_tuning behind rfm_fit_config.tuning (NULL = production): validated like the rest"""
+    base = dict(n_interactions=10, n_users=4, n_items=5, n_user_features=1, n_item_features=1, n_factors=8, max_samples=1,
+                epochs=1, learning_schedule=0, mode=0, rng=1)
+    cfg = _hip.FitConfig(**base)
+    assert not cfg.tuning and lib.rfm_fit_supported(C.byref(cfg)) == _hip.OK
+    assert _hip.make_tuning() is None and _hip.make_tuning({}, debug_flags=0) is None      # (production passes a NULL pointer)
+    good = _hip.make_tuning({"segment_rows": 16, "table_batch": 16}, n_workgroups=8)
+    cfg.tuning = C.pointer(good)
     assert lib.rfm_fit_supported(C.byref(cfg)) == _hip.OK
-    for bad in (dict(tune_segment_rows=33), dict(tune_stripe_rows=-2), dict(tune_stripe_window=-1), dict(tune_table_producers=-1)):
-        c2 = _hip.FitConfig(n_interactions=10, n_users=4, n_items=5, n_user_features=1, n_item_features=1, n_factors=8, max_samples=1,
-                            epochs=1, learning_schedule=0, mode=0, rng=1, **bad)
+    for bad in (dict(segment_rows=33), dict(hot_publications=-2), dict(table_producers=-1), dict(table_batch=6), dict(table_step_pct=500)):
+        c2 = _hip.FitConfig(**base)
+        c2.tuning = C.pointer(_hip.FitTuning(**bad))
         assert lib.rfm_fit_supported(C.byref(c2)) == _hip.ERR_BAD_ARG, bad
     with pytest.raises(ValueError):
-        _hip.tune_kwargs({"stripe_widow": 3})
+        _hip.tune_kwargs({"segment_row": 3})
+    # a kept engine layout lives with its plan: a layout token without a plan token is refused
+    c3 = _hip.FitConfig(layout_token=7, **base)
+    assert lib.rfm_fit_supported(C.byref(c3)) == _hip.ERR_BAD_ARG
+    c3.plan_token = 5
+    assert lib.rfm_fit_supported(C.byref(c3)) == _hip.OK
+
+
+def test_the_fit_config_a_binder_fills_is_small():
+    """the configuration a maintainer binds carries the reference's arguments, the engine's mode / seed and the two
+    tokens of a resident caller -- the lab bench (debug flags, geometry overrides) sits behind one optional pointer"""
+    names = [f for f, _ in _hip.FitConfig._fields_]
+    assert len(names) <= 30 and "tuning" in names
+    assert not [n for n in names if n.startswith(("debug_", "tune_"))]

@@ -313,3 +313,52 @@ def test_resident_session_serves_like_the_host_entry_points():
     trained = s.weights_to_host()
     args2 = (x_uf, x_if, trained["w_i"], trained["w_if"], trained["v_u"], trained["v_i"], trained["v_uf"], trained["v_if"])
     np.testing.assert_array_equal(s.recommend(users, 10, True), _recommend(users, csr, 10, True, *args2))
+
+
+@pytest.mark.parametrize("n_items", [50, 77, 100, 147, 192, 250])
+@pytest.mark.parametrize("factors, item_features", [(8, 0), (24, 3), (50, 0), (64, 4)])
+def test_recommend_for_a_handful_of_users_on_small_catalogues(oracle, n_items, factors, item_features):
+    """with 1 - 10 users and 42 - 256 items the matrix-free path's per-block arrays, each rounded up to 64 floats, did
+    not fit the `scores` area they are carved from and ran into `veff` -- recommendations were silently wrong (item 2's effective
+    factors replaced by the user's row, `filter_previous` zeroing veff[0][0..3]).  Every (users, items, padded k) of the advisor's
+    enumeration against the oracle, with and without the filter; the calls are in ascending user count so that each one runs on the
+    arena the previous, smaller one left behind."""
+    from rankfm_amd import synthetic
+    from rankfm_amd._rankfm import _recommend
+    U, I, F, P, Q = 40, n_items, factors, 1, max(item_features, 1)
+    rng = np.random.default_rng(n_items * 131 + factors)
+    pairs, csr = synthetic.make_interactions(U, I, 300, seed=3)
+    w = synthetic.init_weights(U, I, F, 0, item_features, sigma=0.5, seed=2)
+    w["w_i"] = rng.normal(0, 0.3, I).astype(np.float32)
+    x_uf = np.zeros((U, 1), np.float32)
+    x_if = synthetic.make_features(I, Q, 5) if item_features else np.zeros((I, 1), np.float32)
+    if item_features:
+        w["w_if"] = rng.normal(0, 0.3, Q).astype(np.float32)
+    args = (x_uf, x_if, w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"])
+    for n_users in (1, 2, 3, 5, 8, 10):
+        users = rng.choice(U, n_users, replace=False).astype(np.float32)
+        for flt in (False, True):
+            rec = _recommend(users, csr, 10, flt, *args)
+            ro = oracle.recommend(users, csr.offsets, csr.items, 10, flt, *args)
+            assert (rec == ro).mean() > 0.97, (n_users, flt, rec, ro)      # (identical up to fp32 near-ties in the ranking)
+            if flt:
+                for r, u in zip(rec, users.astype(int)):
+                    assert not set(r.astype(int)) & set(csr.items[csr.offsets[u]:csr.offsets[u + 1]].tolist())
+
+
+def test_matrix_free_and_matrix_recommend_paths_agree():
+    """the matrix-free path picks its candidate blocks from the matrix cores' accumulators and ranks them from fp32 FMA
+    chains; the matrix path (lists longer than 16) ranks the matrix cores' scores themselves.  The same model through both: the first
+    ten of a top-17 (matrix path) are the top-10 (matrix-free path), item for item, on a catalogue with many near-ties."""
+    from rankfm_amd import synthetic
+    from rankfm_amd._rankfm import _recommend
+    U, I, F = 700, 3000, 50
+    rng = np.random.default_rng(11)
+    pairs, csr = synthetic.make_interactions(U, I, 30000, seed=1)
+    w = synthetic.init_weights(U, I, F, 0, 0, sigma=0.05, seed=2)      # (small factors: scores 1e-2 apart and closer)
+    w["w_i"] = (rng.integers(0, 40, I) * 0.01).astype(np.float32)
+    args = (np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32), w["w_i"], w["w_if"], w["v_u"], w["v_i"], w["v_uf"], w["v_if"])
+    users = np.arange(U, dtype=np.float32)
+    for flt in (False, True):
+        short, long_ = _recommend(users, csr, 10, flt, *args), _recommend(users, csr, 17, flt, *args)
+        assert (short == long_[:, :10]).mean() > 0.999

@@ -31,8 +31,7 @@ def _oracle_epoch(oracle, sh, w, max_samples, epoch, seed, lr, geometry=None, **
     perms = order.epoch_positions(sh["csr_offsets"], seed, epoch, (geometry or {}).get("segment_rows") or None)[None, :].astype(np.int32)
     return oracle.fit(pairs_csr, sw_csr, sh["csr_offsets"], sh["csr_items"], sh["x_uf"], sh["x_if"], w["w_i"], w["w_if"], w["v_u"],
                       w["v_i"], w["v_uf"], w["v_if"], 0.01, 0.1, lr, "constant", 0.25, max_samples, 1, perms=perms,
-                      rng_mode=oracle.RNG_COUNTER, seed=seed, membership="binary", epoch_begin=epoch, want_negatives=True, **oracle_kw,
-                      **order.oracle_stripes(sh["csr_offsets"], seed, [epoch], geometry, len(w["w_i"])))
+                      rng_mode=oracle.RNG_COUNTER, seed=seed, membership="binary", epoch_begin=epoch, want_negatives=True, **oracle_kw)
 
 
 def _trained_then_one_epoch(oracle, sh, max_samples, warm_epochs, seed, lr=0.1, damped=False):

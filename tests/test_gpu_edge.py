@@ -150,8 +150,6 @@ def test_epoch_parts_compose_to_the_whole_epoch():
     sw = np.ones(len(pairs), np.float32)
     w0 = synthetic.init_weights(200, 150, 16, seed=2)
     z_u, z_i = np.zeros((200, 1), np.float32), np.zeros((150, 1), np.float32)
-    # (one group, the default uniform sampler -- with the opt-in stripes the schedule restarts with every launch, so the slices
-    # draw other, equally valid negatives than the whole epoch does: checked below)
     whole = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
     r0 = whole.run(epochs=1)
     sliced = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
@@ -166,13 +164,6 @@ def test_epoch_parts_compose_to_the_whole_epoch():
     assert draws == r0["n_draws"][0] == len(pairs) and ll == pytest.approx(r0["log_likelihood"][0], rel=1e-9)
     with pytest.raises(ValueError):
         sliced.run(epochs=1, part=(5, 5))
-    from conftest import stripes_built
-    if not stripes_built():               # (a library built with RFM_NO_STRIPES=1)
-        return
-    striped = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1, negative_stripes=True)
-    rs = [striped.run(epochs=1, part=(k, 5)) for k in range(5)]
-    assert sum(int(r["n_draws"][0]) for r in rs) == len(pairs)
-    assert sum(float(r["log_likelihood"][0]) for r in rs) == pytest.approx(r0["log_likelihood"][0], rel=0.02)
 
 
 def test_duplicate_heavy_user_with_more_rows_than_items_trains(oracle):

@@ -85,26 +85,22 @@ def _problem(U, I, N, F, seed, n_uf=0, n_if=0, sigma=0.1, random_sw=False):
     return pairs, csr, sw, x_uf, x_if, w
 
 
-def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1, schedule="constant", geometry=None, plain_sampler=False,
-                            **oracle_kw):
+def _oracle_in_engine_order(oracle, prob, w0, max_samples, epochs, seed, lr=0.1, schedule="constant", geometry=None, **oracle_kw):
     """The sequential CPU oracle on exactly the order and draws of the Hogwild segments kernel: interactions re-ordered to
-    CSR positions (the kernel keys its counter RNG by CSR position), visiting order and -- given the launch `geometry` the
-    engine reported -- the negative stripe of every row from rankfm_amd.order."""
+    CSR positions (the kernel keys its counter RNG by CSR position), visiting order from rankfm_amd.order with the segment
+    length of the launch `geometry` the engine reported."""
     from rankfm_amd import order
     pairs, csr, sw, x_uf, x_if, _ = prob
     by_csr = np.lexsort((pairs[:, 1], pairs[:, 0]))
     pairs_csr = np.ascontiguousarray(pairs[by_csr])
     assert np.array_equal(pairs_csr[:, 1], csr.items)
     sw_csr = np.ascontiguousarray(sw[by_csr])
-    seg_rows = (geometry or {}).get("segment_rows") or None          # the plan's segment length (16 with negative stripes)
+    seg_rows = (geometry or {}).get("segment_rows") or None          # the plan's segment length
     perms = np.stack([order.epoch_positions(csr.offsets, seed, e, seg_rows) for e in range(epochs)]).astype(np.int32)
     o = {k: v.copy() for k, v in w0.items()}
     out = oracle.fit(pairs_csr, sw_csr, csr.offsets, csr.items, x_uf, x_if, o["w_i"], o["w_if"], o["v_u"], o["v_i"], o["v_uf"],
                      o["v_if"], 0.01, 0.1, lr, schedule, 0.25, max_samples, epochs, perms=perms, rng_mode=oracle.RNG_COUNTER,
-                     seed=seed, membership="binary", want_negatives=len(pairs) <= 1_000_000, **oracle_kw,
-                     # plain_sampler: the REFERENCE'S sampler (every draw uniform over the catalogue, rankfm/_rankfm.pyx:250-253) on the
-                     # engine's order, instead of the engine's own negative stripes
-                     **({} if plain_sampler else order.oracle_stripes(csr.offsets, seed, range(epochs), geometry, len(w0["w_i"]))))
+                     seed=seed, membership="binary", want_negatives=len(pairs) <= 1_000_000, **oracle_kw)
     return o, out
 
 
@@ -139,20 +135,6 @@ def test_hogwild_kernel_on_one_group_is_the_sequential_algorithm(oracle, F, max_
         np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg=k)
     np.testing.assert_allclose(rep["log_likelihood"], out["ll64"], rtol=1e-4)
     assert np.array_equal(rep["n_draws"], out["nsamp"].sum(axis=1))
-
-
-@pytest.mark.parametrize("F, flags", [(64, 1), (64, 3), (16, 1), (32, 1), (128, 1), (96, 1)])
-def test_stripe_kernel_on_one_group_is_the_sequential_algorithm(oracle, F, flags):
-    """The OPT-IN stripe sampler (EngineOptions.negative_stripes, sgd_segments_kernel<STRIPE>: negatives from an LDS-held stripe, their
-    updates combined in LDS and published per window, rows pipelined) restricted to one row group: a sequential program that must
-    reproduce the oracle run on the same order and -- through the host mirror of the stripe schedule (rankfm_amd.order) -- the same
-    negatives, to the serial tolerance.  Full factor rows only (the planner's condition for stripes)."""
-    prob = _problem(U=120, I=90, N=3000, F=F, seed=F + 1, random_sw=True)
-    g, rep, o, out = _both(oracle, prob, 1, epochs=2, seed=9, engine_kw=dict(debug_flags=flags, negative_stripes=True))
-    assert rep["geometry"]["stripe_rows"] > 0
-    for k in WEIGHTS:
-        np.testing.assert_allclose(g[k], o[k], rtol=SERIAL_RTOL, atol=SERIAL_ATOL, err_msg=k)
-    np.testing.assert_allclose(rep["log_likelihood"], out["ll64"], rtol=1e-4)
 
 
 @pytest.mark.parametrize("F, n_uf, n_if", [(64, 32, 32), (16, 4, 5), (20, 8, 8), (32, 0, 6), (128, 20, 32), (48, 7, 0), (8, 1, 1)])
@@ -315,57 +297,36 @@ def test_ranking_quality_matches_oracle_on_planted_data(oracle):
     np.testing.assert_allclose(np.mean(norms["gpu"], axis=0), np.mean(norms["oracle"], axis=0), rtol=0.02)
 
 
-@pytest.mark.parametrize("sampler", ["uniform", "stripes"])
-def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem, sampler):
-    """BASELINE config 2 at FULL size, default (full-chip) concurrency: two epochs of Hogwild on the GPU against two epochs of the
-    sequential CPU oracle on the same visiting order.
-      uniform  the production default and what bench.py times: every negative drawn uniformly over the catalogue like the reference
-               (rankfm/_rankfm.pyx:250-253) by the counter RNG; the oracle draws the very same negatives.
-      stripes  the opt-in fast sampler, twice: (a) against the oracle on the engine's own negatives (stripe schedule mirrored by
-               rankfm_amd.order) -- what asynchronous execution and the step damping change -- and (b) against the oracle with the
-               REFERENCE'S sampler, which holds the stripe sampler itself to the reference's trajectory.
-    Default: norms within 1 %, log-likelihood (against the oracle's double sum) within 1.0 % in the first epoch and 0.5 % in the second;
-    stripes: 2 %, 1.5 % / 1.5 %.
-    (The log-likelihood does not see what the stripes cost in RANKING quality: tests/test_gpu_quality.py does.)"""
+def test_hogwild_full_size_config2_tracks_sequential_oracle(oracle, c2_problem):
+    """BASELINE config 2 at FULL size, default (full-chip) concurrency -- what bench.py times: two epochs of Hogwild on the GPU against
+    two epochs of the sequential CPU oracle on the same visiting order and the very same negatives (every negative drawn uniformly over
+    the catalogue like the reference, rankfm/_rankfm.pyx:250-253, by the counter RNG).
+    Norms within 1 %, log-likelihood (against the oracle's double sum) within 1.0 % in the first epoch and 0.5 % in the second."""
     from rankfm_amd import synthetic
     from rankfm_amd.engine import DeviceSession
     U, I, N, F, pairs, csr = c2_problem
     w = synthetic.init_weights(U, I, F, seed=1492)
     sw = np.ones(N, np.float32)
     x_uf, x_if = np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32)
-    sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=1, seed=1492, negative_stripes=sampler == "stripes")
+    sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=1, seed=1492)
     rep = sess.run(epochs=2)
     g = sess.weights_to_host()
     geo = sess.geometry()
-    assert (geo["stripe_rows"] > 0) == (sampler == "stripes")
     prob = (pairs, csr, sw, x_uf, x_if, None)
-    sides = [("the engine's negatives", _oracle_in_engine_order(oracle, prob, w, 1, 2, 1492, geometry=geo), 0.98)]
-    if sampler == "stripes":
-        # (other negatives than the engine drew: the trajectories agree in law -- norms, log-likelihood -- not element by element:
-        # the correlation of v_i with this oracle was 0.85 ... 0.94 over runs and is not asserted)
-        sides.append(("the reference's sampler", _oracle_in_engine_order(oracle, prob, w, 1, 2, 1492, geometry=geo, plain_sampler=True), None))
-    # Measured over four runs each (tools/ll_margins.py, profiles/r03_notes.md), epochs 1 / 2:
-    #   uniform      +0.60 % / +0.17 %, norms v_u +0.02 %, v_i +0.12 %, w_i +0.66 %;  of that +0.38 % / +0.19 % (and +0.54 % of |w_i|) is
-    #                the step damping by itself (the SEQUENTIAL oracle with the engine's step scales): asynchrony costs +0.22 % / -0.02 %;
-    #   stripes (a)  +0.43 ... +0.59 % / -0.38 ... -0.51 %, norms v_u +0.05 %, v_i +0.19 %, w_i -0.57 ... -0.70 %;
-    #   stripes (b)  +0.17 ... +0.33 % / -0.49 ... -0.62 %, norms v_u +0.32 %, v_i +0.62 %, w_i -0.47 ... -0.61 %.
-    for name, (oo, oout), corr in sides:
-        print("full-size config 2, %s sampler, vs the oracle with %s: LL gpu/oracle - 1 =" % (sampler, name), rep["log_likelihood"] / oout["ll64"] - 1.0,
-              " norms gpu/oracle - 1 =", [float(np.linalg.norm(g[k]) / np.linalg.norm(oo[k]) - 1.0) for k in ("v_u", "v_i", "w_i")])
-        # the default: 1.0 % / 0.5 %, norms 1 % (round 4, item damping on both sides of a pair + dynamic segment order: measured
-        # +0.39 ... +0.40 % / -0.04 %, norms +0.09 / +0.16 / +0.12 % -- the first epoch's +0.4 % is the hot head's slower start under
-        # the damping, the sequential stand-in shows +0.18 %); the frozen opt-in stripes: 1.5 % / 1.5 % / 2 %, below
-        # (The stripes' second epoch has TWO modes from box to box, with one and the same stripe kernel binary: -0.35 ... -0.62 % on every box
-        #  of rounds 3 - 4 until the last hours of round 4, then -0.79 ... -1.09 % (|w_i| -1.2 %) on about half of them, the default's figures
-        #  beside it unchanged to the digit (+0.40 % / -0.04 %).  The stripe workgroups' windows are meant to run in step and nothing but
-        #  their equal pace keeps them there: profiles/r04_notes.md section 12.  The opt-in path is frozen, so its guard is 1.5 % / 1.5 %.)
-        tight = sampler == "uniform"
-        _assert_statistical_parity(g, rep, oo, oout, ll_tol=0.010 if tight else 0.015, norm_tol=0.01 if tight else 0.02, corr=corr)
-        np.testing.assert_allclose(rep["log_likelihood"][1:], oout["ll64"][1:], rtol=0.005 if tight else 0.015)
+    oo, oout = _oracle_in_engine_order(oracle, prob, w, 1, 2, 1492, geometry=geo)
+    # Measured (tools/ll_margins.py, tools/pub_margin.py), epochs 1 / 2: round 3 +0.60 % / +0.17 %, norms v_u +0.02 %, v_i +0.12 %, w_i +0.66 %
+    # (of that +0.38 % / +0.19 % and +0.54 % of |w_i| were the one-sided step damping); round 4 (item damping on both sides of a pair,
+    # dynamic segment order) +0.39 ... +0.40 % / -0.04 %, norms +0.09 / +0.16 / +0.12 %; round 5 (segment-major item rows, 32 publications,
+    # 192 workgroups) +0.55 % / -0.05 %, norms +0.03 / +0.13 / +0.36 % -- the first epoch's deviation is the hot head's slower start under
+    # the damping (the sequential stand-in shows +0.18 %) and grows with the publication period.
+    print("full-size config 2 vs the oracle on the engine's order and negatives: LL gpu/oracle - 1 =", rep["log_likelihood"] / oout["ll64"] - 1.0,
+          " norms gpu/oracle - 1 =", [float(np.linalg.norm(g[k]) / np.linalg.norm(oo[k]) - 1.0) for k in ("v_u", "v_i", "w_i")])
+    _assert_statistical_parity(g, rep, oo, oout, ll_tol=0.010, norm_tol=0.01, corr=0.98)
+    np.testing.assert_allclose(rep["log_likelihood"][1:], oout["ll64"][1:], rtol=0.005)
 
 
-@pytest.mark.parametrize("damping, stripes", [(-1.0, False), (1e9, False), (1e9, True)])
-def test_hogwild_conserves_item_factor_sums(c2_problem, damping, stripes):
+@pytest.mark.parametrize("damping", [-1.0, 1e9])
+def test_hogwild_conserves_item_factor_sums(c2_problem, damping):
     """Size-independent property at BASELINE config-2 scale: with alpha -> 0 every step adds +d to v_i[i] and -d to
     v_i[j] (rankfm/_rankfm.pyx:309-310) and +/-g to w_i, so column sums of v_i and the sum of w_i are invariants of
     ANY interleaving -- provided no update is lost.  Atomic adds keep them; a racy read-modify-write would not."""
@@ -376,12 +337,10 @@ def test_hogwild_conserves_item_factor_sums(c2_problem, damping, stripes):
     before = w["v_i"].astype(np.float64).sum(axis=0)
     sess = DeviceSession(pairs, np.ones(N, np.float32), csr.offsets, csr.items, np.zeros((U, 1), np.float32),
                          np.zeros((I, 1), np.float32), w, alpha=0.0, beta=0.0, max_samples=1, seed=1492,
-                         hogwild_damping=damping, negative_stripes=stripes)
+                         hogwild_damping=damping)
     # damping rescales the positive item's step only, so it must not act here: -1 switches it (and the hot-row LDS
-    # accumulation) off; 1e9 keeps every scale at 1 but leaves the hot-row accumulators ON -- they must not lose updates either;
-    # with the opt-in stripe sampler the negatives' updates go through LDS pending sums and per-window publications as well
+    # accumulation) off; 1e9 keeps every scale at 1 but leaves the hot-row accumulators ON -- they must not lose updates either
     rep = sess.run(epochs=1)
-    assert (sess.geometry()["stripe_rows"] > 0) == stripes
     h = sess.weights_to_host()
     after = h["v_i"].astype(np.float64).sum(axis=0)
     moved = np.abs(h["v_i"] - w["v_i"]).astype(np.float64).sum(axis=0)      # total |delta| per column: O(1e4)
@@ -436,7 +395,7 @@ def test_two_user_shards_with_damped_delta_merge_track_the_oracle(oracle):
     does (start + scale * sum of deltas, SharedTables).  The result must track single-run sequential training of the whole
     data: during the first epoch each shard is blind to the other's item updates (one exchange per epoch), so that epoch's
     log-likelihood lags by a few percent (6 % allowed, measured +3.6 ... +3.8 %); the damped merge then overshoots a little
-    (second epoch 3 % allowed, measured -1.8 ... -2.5 % depending on the stripe window) and the run settles on the oracle's
+    (second epoch 3 % allowed, measured -1.8 ... -2.5 %) and the run settles on the oracle's
     trajectory (third = final epoch within 2 %, measured -1.4 ... -1.6 %); factor norms within 5 % (the item biases, which
     settle fastest, are the most sensitive: +3 % here)."""
     import torch

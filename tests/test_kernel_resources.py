@@ -35,13 +35,13 @@ def test_the_bench_kernel_and_the_warp_kernels_do_not_spill(kernels):
     for kpl in (1, 2, 4):
         for fresh in ("false", "true"):
             for split in ("true", "false"):
-                for r in pick(kernels, "sgd_segments_kernel<16, %d, %s, true, false, false, %s>" % (kpl, fresh, split)):
+                for r in pick(kernels, "sgd_segments_kernel<16, %d, %s, true, false, %s>" % (kpl, fresh, split)):
                     assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] <= 128, r
     # ... and no segment-major BPR instantiation the host can launch (k = 16 ... 96) spills either (k = 128 stays row-major: rfm_api.hip)
     for kpl in (3, 6):
-        for r in pick(kernels, "sgd_segments_kernel<16, %d, false, true, false, false, true>" % kpl):
+        for r in pick(kernels, "sgd_segments_kernel<16, %d, false, true, false, true>" % kpl):
             assert r["vgpr_spill"] == 0 and r["scratch"] == 0, r
-    assert not [r for r in kernels if r["kernel"].startswith("sgd_segments_kernel<16, 8, false, true, false, false, true>")]
+    assert not [r for r in kernels if r["kernel"].startswith("sgd_segments_kernel<16, 8, false, true, false, true>")]
     # configs 3 / 5 and every other factor count: the WARP state machine
     for r in pick(kernels, "sgd_warp_kernel<16, "):
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, r

@@ -4,7 +4,7 @@ same data and the same initial weights; the measured epochs are INTERLEAVED (A B
 
     python tools/ab_kernel.py --config C2 --variants "base;flags=128;flags=256;flags=384" [--epochs 6] [--rounds 4]
 
-A variant is a ','-separated list of  flags=<debug_flags>  damping=<M>  workgroups=<n>  stripes  <tune_name>=<int>.
+A variant is a ','-separated list of  flags=<debug_flags>  damping=<M>  workgroups=<n>  <tune_name>=<int>.
 Prints per variant the SGD launch time (HIP events inside rfm_fit_device): min / median / mean over the measured epochs, the
 updates/s of the median, the log-likelihood of the last epoch (a sanity check that the variant still trains the same model) and
 the norms of v_u, v_i, w_i.  Measurement tooling, not product."""
@@ -21,11 +21,8 @@ from rankfm_amd import synthetic                       # noqa: E402
 
 
 def parse_variant(text):
-    kw = dict(debug_flags=0, hogwild_damping=0.0, n_workgroups=0, negative_stripes=False, tune={})
+    kw = dict(debug_flags=0, hogwild_damping=0.0, n_workgroups=0, tune={})
     for part in [p for p in text.split(",") if p and p != "base"]:
-        if part == "stripes":
-            kw["negative_stripes"] = True
-            continue
         k, v = part.split("=")
         if k == "flags":
             kw["debug_flags"] = int(v)

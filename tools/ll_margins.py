@@ -5,8 +5,7 @@ float accumulator `ll` is printed beside it: it is off by -0.5 % ... +0.6 % at t
 
     python tools/ll_margins.py [--runs 4] [--configs C2,C3,C4] [--procs 8]
 
-Config 2 also runs the oracle on the engine's order with the REFERENCE'S sampler (whole-catalogue draws, rankfm/_rankfm.pyx:250-253)
-instead of the engine's negative stripes, and -- `--damped` -- under the engine's step damping (what is left is asynchrony alone).
+`--damped` also runs the oracle under the engine's step damping (what is left between the two is asynchrony alone).
 The oracle runs of all repetitions are farmed out to a process pool that is forked BEFORE the GPU is touched.
 Test infrastructure (uses oracle/), not product."""
 import argparse
@@ -46,8 +45,6 @@ def oracle_task(spec):
     epochs = spec["epochs"]
     perms = np.stack([order.epoch_positions(d["csr_offsets"], spec["seed"], e, geo.get("segment_rows") or None) for e in epochs]).astype(np.int32)
     extra = {}
-    if spec.get("stripes"):
-        extra.update(order.oracle_stripes(d["csr_offsets"], spec["seed"], epochs, geo, len(w["w_i"])))
     if spec.get("steps"):
         s = np.load(spec["steps"])
         extra.update(pos_step=s["pos"], user_step=s["user"], neg_step=s["pos"])      # (an item's scale applies on either side of the pair)
@@ -111,30 +108,25 @@ def main():
     # ---- config 2: two epochs from the initial weights ---------------------------------------------------------------------
     if "C2" in configs:
         w0p = save_weights(DATA["C2"]["weights"], "c2_init")
-        for variant, flags in (("stripes", 0), ("nostripes", 8)):     # (opt-in stripe sampler / the default uniform sampler)
-            for r in range(a.runs):
-                s = session("C2", max_samples=1, seed=1492, negative_stripes=variant == "stripes")
-                with gpu():
-                    rep = s.run(epochs=2)
-                g = s.weights_to_host()
-                runs["C2:%s:%d" % (variant, r)] = dict(ll=rep["log_likelihood"].copy(), ms=rep["sgd_kernel_ms"].copy(),
-                                                     norms={k: float(np.linalg.norm(g[k])) for k in WEIGHTS})
-                if r == 0:
-                    geo = s.geometry()
-                    print("C2 %s geometry %s" % (variant, {k: geo[k] for k in ("workgroups", "working_groups", "stripe_rows", "stripe_window", "segment_rows")}), flush=True)
-                    submit(tag="C2:%s:oracle" % variant, data="C2", weights=w0p, max_samples=1, epochs=[0, 1], seed=1492, lr=0.1,
-                           geometry_order=geo, stripes=variant == "stripes")
-                    if variant == "stripes":     # the reference's sampler on the same order
-                        submit(tag="C2:stripes:plain_oracle", data="C2", weights=w0p, max_samples=1, epochs=[0, 1], seed=1492, lr=0.1,
-                               geometry_order=geo, stripes=False)
-                    if a.damped:
-                        sys.path.insert(0, os.path.join(ROOT, "tools"))
-                        pos, user = s.step_scales()
-                        sp = os.path.join(TMP, "c2_steps_%s.npz" % variant)
-                        np.savez(sp, pos=pos, user=user)
-                        submit(tag="C2:%s:damped_oracle" % variant, data="C2", weights=w0p, max_samples=1, epochs=[0, 1], seed=1492, lr=0.1,
-                               geometry_order=geo, stripes=variant == "stripes", steps=sp)
-                del s
+        for r in range(a.runs):
+            s = session("C2", max_samples=1, seed=1492)
+            with gpu():
+                rep = s.run(epochs=2)
+            g = s.weights_to_host()
+            runs["C2:%d" % r] = dict(ll=rep["log_likelihood"].copy(), ms=rep["sgd_kernel_ms"].copy(),
+                                     norms={k: float(np.linalg.norm(g[k])) for k in WEIGHTS})
+            if r == 0:
+                geo = s.geometry()
+                print("C2 geometry %s" % {k: geo[k] for k in ("workgroups", "working_groups", "segment_rows")}, flush=True)
+                submit(tag="C2:oracle", data="C2", weights=w0p, max_samples=1, epochs=[0, 1], seed=1492, lr=0.1, geometry_order=geo)
+                if a.damped:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    pos, user = s.step_scales()
+                    sp = os.path.join(TMP, "c2_steps.npz")
+                    np.savez(sp, pos=pos, user=user)
+                    submit(tag="C2:damped_oracle", data="C2", weights=w0p, max_samples=1, epochs=[0, 1], seed=1492, lr=0.1,
+                           geometry_order=geo, steps=sp)
+            del s
     # ---- config 3: three epochs of training, then one compared epoch from the same weights ------------------------------------
     if "C3" in configs:
         for r in range(a.runs):
@@ -147,14 +139,12 @@ def main():
             g = s.weights_to_host()
             runs["C3:%d" % r] = dict(ll=rep["log_likelihood"].copy(), ms=rep["sgd_kernel_ms"].copy(), draws=rep["n_draws"].copy(),
                                     norms={k: float(np.linalg.norm(g[k])) for k in WEIGHTS})
-            submit(tag="C3:%d:oracle" % r, data="C2", weights=wp, max_samples=50, epochs=[3], seed=1492, lr=0.1, geometry_order=s.geometry(),
-                   stripes=False)
+            submit(tag="C3:%d:oracle" % r, data="C2", weights=wp, max_samples=50, epochs=[3], seed=1492, lr=0.1, geometry_order=s.geometry())
             if a.damped and r == 0:
                 pos, user = s.step_scales()
                 sp = os.path.join(TMP, "c3_steps.npz")
                 np.savez(sp, pos=pos, user=user)
-                submit(tag="C3:0:damped_oracle", data="C2", weights=wp, max_samples=50, epochs=[3], seed=1492, lr=0.1, geometry_order=s.geometry(),
-                       stripes=False, steps=sp)
+                submit(tag="C3:0:damped_oracle", data="C2", weights=wp, max_samples=50, epochs=[3], seed=1492, lr=0.1, geometry_order=s.geometry(), steps=sp)
             del s
     # ---- config 4, one GPU's share: first epoch from the initial weights, second epoch from the GPU's weights -----------------
     if "C4" in configs:
@@ -175,8 +165,8 @@ def main():
             runs["C4:e1:%d" % r] = dict(ll=rep1["log_likelihood"].copy(), ms=rep1["sgd_kernel_ms"].copy(), norms={k: float(np.linalg.norm(g1[k])) for k in WEIGHTS})
             runs["C4:e2:%d" % r] = dict(ll=rep2["log_likelihood"].copy(), ms=rep2["sgd_kernel_ms"].copy(), norms={k: float(np.linalg.norm(g2[k])) for k in WEIGHTS})
             if r == 0:
-                submit(tag="C4:e1:oracle", data="C4", weights=w0p, max_samples=1, epochs=[0], seed=1492, lr=lr, geometry_order=s.geometry(), stripes=False)
-            submit(tag="C4:e2:%d:oracle" % r, data="C4", weights=wp, max_samples=1, epochs=[1], seed=1492, lr=lr, geometry_order=s.geometry(), stripes=False)
+                submit(tag="C4:e1:oracle", data="C4", weights=w0p, max_samples=1, epochs=[0], seed=1492, lr=lr, geometry_order=s.geometry())
+            submit(tag="C4:e2:%d:oracle" % r, data="C4", weights=wp, max_samples=1, epochs=[1], seed=1492, lr=lr, geometry_order=s.geometry())
             del s
     print("GPU runs done after %.1f s; waiting for %d oracle runs" % (time.time() - t0, len(pending)), flush=True)
     ora = {}
@@ -198,12 +188,9 @@ def main():
     print("\n==== results (oracle float-sum error: " + ", ".join("%s %s" % (k, fmt(v["ll"] / v["ll64"] - 1.0)) for k, v in sorted(ora.items())) + ")")
     for r in range(a.runs):
         if "C2" in configs:
-            compare("C2:stripes:%d" % r, "C2:stripes:oracle")
-            compare("C2:stripes:%d" % r, "C2:stripes:plain_oracle")
-            compare("C2:nostripes:%d" % r, "C2:nostripes:oracle")
+            compare("C2:%d" % r, "C2:oracle")
             if a.damped:
-                compare("C2:stripes:%d" % r, "C2:stripes:damped_oracle")
-                compare("C2:nostripes:%d" % r, "C2:nostripes:damped_oracle")
+                compare("C2:%d" % r, "C2:damped_oracle")
         if "C3" in configs:
             compare("C3:%d" % r, "C3:%d:oracle" % r)
             if a.damped and r == 0:
@@ -212,10 +199,9 @@ def main():
             compare("C4:e1:%d" % r, "C4:e1:oracle", WEIGHTS)
             compare("C4:e2:%d" % r, "C4:e2:%d:oracle" % r, WEIGHTS)
     if a.damped and "C2" in configs:
-        for v in ("stripes", "nostripes"):
-            d, p = ora["C2:%s:damped_oracle" % v], ora["C2:%s:oracle" % v]
-            print("C2 %s: damped / plain sequential oracle - 1: LL %s  |w_i| %+.2f%%" % (v, fmt(d["ll64"] / p["ll64"] - 1.0),
-                                                                                      100.0 * (d["norms"]["w_i"] / p["norms"]["w_i"] - 1.0)))
+        d, p = ora["C2:damped_oracle"], ora["C2:oracle"]
+        print("C2: damped / plain sequential oracle - 1: LL %s  |w_i| %+.2f%%" % (fmt(d["ll64"] / p["ll64"] - 1.0),
+                                                                                  100.0 * (d["norms"]["w_i"] / p["norms"]["w_i"] - 1.0)))
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@ ap.add_argument("--sigma", type=float, default=0.1)
 ap.add_argument("--no-oracle", action="store_true")
 ap.add_argument("--debug-flags", default="0")
 ap.add_argument("--lr", type=float, default=0.1)
-ap.add_argument("--variants", default="", help="geometry-override variants (rfm_fit_config tune_*): 'stripe_window=12,segment_rows=32;stripe_rows=-1'")
+ap.add_argument("--variants", default="", help="geometry-override variants (rfm_fit_tuning): 'segment_rows=16;hot_publications=24'")
 a = ap.parse_args()
 U, I, N, F = a.users, a.items, a.rows, a.factors
 pairs, csr = synthetic.make_interactions(U, I, N, seed=0, zipf_s=a.zipf)

@@ -28,7 +28,7 @@ ap.add_argument("--schedule", default="constant")
 ap.add_argument("--workgroups", default="0")
 ap.add_argument("--dampings", default="0")
 ap.add_argument("--variants", default="", help="engine variants for the GPU sides, ';'-separated; a variant is a ','-separated list of "
-                "'stripes' (the opt-in stripe sampler) and geometry overrides (rfm_fit_config tune_*): e.g. ';stripes;stripes,segment_rows=32'")
+                "geometry overrides (rfm_fit_tuning): e.g. ';segment_rows=16'")
 ap.add_argument("--seed0", type=int, default=0)
 ap.add_argument("--large", action="store_true", help="synthetic.make_planted_large (config-2-sized problems) instead of make_planted")
 ap.add_argument("--degree", type=float, default=60.0, help="mean degree of make_planted_large")
@@ -41,7 +41,7 @@ T0 = time.time()
 
 def engine_of(variant, **kw):
     tune = {x.split("=")[0]: int(x.split("=")[1]) for x in variant.split(",") if "=" in x}
-    return EngineOptions(negative_stripes="stripes" in variant.split(","), tune=tune, **kw)
+    return EngineOptions(tune=tune, **kw)
 
 
 for seed in range(a.seed0, a.seed0 + a.seeds):
