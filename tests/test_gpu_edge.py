@@ -209,3 +209,74 @@ def test_recommend_for_a_user_who_has_seen_nearly_everything(oracle):
     assert not np.isnan(rec).any()
     assert set(rec[0].astype(int)) <= set(unseen.tolist()) and len(set(rec[0].astype(int))) == n_rec
     assert np.array_equal(rec, ro)
+
+
+def test_kept_engine_layout_is_the_same_training_bit_for_bit_on_one_group():
+    """rfm_fit_config.keep_layout (DeviceSession(keep_layout=True)): between calls the item-side weights stay in the engine's working layout
+    inside the workspace -- here the padded biases; the caller's arrays are stale until they are exported.  One row group is a sequential
+    program, so a session that keeps the layout over calls of DIFFERENT lengths (the workspace is re-allocated in between: the session
+    exports first) must land bit for bit on the weights of a session that converts on every call, and `predict` on the live session must
+    serve the current weights."""
+    from rankfm_amd import synthetic
+    from rankfm_amd.engine import DeviceSession
+    U, I, F = 200, 150, 16
+    pairs, csr = synthetic.make_interactions(U, I, 6000, seed=8)
+    sw = np.ones(len(pairs), np.float32)
+    w0 = synthetic.init_weights(U, I, F, seed=2)
+    z_u, z_i = np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32)
+    plain = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1)
+    kept = DeviceSession(pairs, sw, csr.offsets, csr.items, z_u, z_i, w0, seed=3, debug_flags=1, keep_layout=True)
+    e = 0
+    for n in (1, 1, 3, 2, 9):
+        ra, rb = plain.run(epochs=n, epoch_begin=e), kept.run(epochs=n, epoch_begin=e)
+        assert kept._layout_token != 0                                        # (the call did keep it)
+        np.testing.assert_array_equal(ra["log_likelihood"], rb["log_likelihood"])
+        e += n
+    stale = kept.weights["w_i"].cpu().numpy()
+    a, b = plain.weights_to_host(), kept.weights_to_host()
+    assert not np.array_equal(stale, b["w_i"])                                # (the caller's array WAS stale, and the export refreshed it)
+    for k in WEIGHTS:
+        assert np.array_equal(a[k], b[k]), k
+    idx = np.stack([np.arange(50) % U, np.arange(50) % I], 1).astype(np.float32)
+    kept.run(epochs=1, epoch_begin=e)
+    plain.run(epochs=1, epoch_begin=e)
+    np.testing.assert_array_equal(kept.predict(idx), plain.predict(idx))
+    # a call that is refused before anything runs leaves plan and layout as they were
+    with pytest.raises(ValueError):
+        kept.run(epochs=1, part=(5, 5))
+    assert kept._layout_token != 0
+    np.testing.assert_array_equal(kept.weights_to_host()["v_i"], plain.weights_to_host()["v_i"])
+
+
+def test_kept_engine_layout_loses_no_update_at_config2_scale(c2_problem):
+    """The production kernel of config 2 on a kept layout: segment-major factor rows, padded biases and the hot-row bins stay in the
+    workspace over four calls (1 + 1 + 2 + 5 epochs; the last one re-allocates the workspace); what the workgroups leave in the bins when a
+    launch ends is folded in by the epoch tail and by the export.  With alpha = 0 the column sums of v_i and the sum of w_i are invariants of
+    any interleaving iff no update is lost (tests/test_gpu_parity.py::test_hogwild_conserves_item_factor_sums) -- also across the layout's
+    round trips."""
+    from rankfm_amd import synthetic
+    from rankfm_amd.engine import DeviceSession
+    U, I, N, F, pairs, csr = c2_problem
+    w = synthetic.init_weights(U, I, F, seed=1492)
+    before = w["v_i"].astype(np.float64).sum(axis=0)
+    sess = DeviceSession(pairs, np.ones(N, np.float32), csr.offsets, csr.items, np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32), w,
+                         alpha=0.0, beta=0.0, max_samples=1, seed=1492, hogwild_damping=1e9, keep_layout=True)
+    lls, e = [], 0
+    for n in (1, 1, 2, 5):
+        rep = sess.run(epochs=n, epoch_begin=e)
+        assert sess._layout_token & 4 and sess._layout_token & 2 and (sess._layout_token >> 8) > 0      # segment-major rows, padded biases, hot slots
+        lls += list(rep["log_likelihood"])
+        e += n
+    h = sess.weights_to_host()
+    after = h["v_i"].astype(np.float64).sum(axis=0)
+    moved = np.abs(h["v_i"] - w["v_i"]).astype(np.float64).sum(axis=0)
+    assert np.all(np.abs(after - before) <= 2e-5 * moved + 1e-3), (np.abs(after - before).max(), moved.min())
+    assert abs(float(h["w_i"].astype(np.float64).sum())) <= 2e-5 * float(np.abs(h["w_i"]).astype(np.float64).sum()) + 1e-3
+    assert all(np.isfinite(lls)) and lls[-1] > lls[0]
+    # ... and the exported weights are what the engine goes on training from: one more epoch on a fresh session started from them tracks
+    # the kept session's next epoch
+    rep_k = sess.run(epochs=1, epoch_begin=e)
+    fresh = DeviceSession(pairs, np.ones(N, np.float32), csr.offsets, csr.items, np.zeros((U, 1), np.float32), np.zeros((I, 1), np.float32), h,
+                          alpha=0.0, beta=0.0, max_samples=1, seed=1492, hogwild_damping=1e9)
+    rep_f = fresh.run(epochs=1, epoch_begin=e)
+    assert rep_f["log_likelihood"][0] == pytest.approx(rep_k["log_likelihood"][0], rel=2e-3)
