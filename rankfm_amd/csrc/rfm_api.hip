@@ -264,12 +264,15 @@ static rfm_fit_tuning tuning_of(const rfm_fit_config *c) {
 }
 
 constexpr int kMaxHot = 64;                      // hot-row accumulator slots per workgroup (LDS: kMaxHot * (F + 2) floats)
-// Publications of a hot row per epoch and workgroup (tune_hot_publications).  A publication is not only five atomic requests into the
-// bins: with 48 of them every seventh row of config 2 publishes, i.e. nearly every second wavefront row step runs the publication
-// block for one of its four rows.  Measured at full size against the sequential oracle (tools/pub_margin.py, profiles/r05_notes.md;
-// epoch 1 / 2 log-likelihood, |w_i|, kernel): 48: +0.40 % / -0.04 %, +0.25 %, 2.67 ms; 32: +0.55 % / -0.05 %, +0.36 %, 2.58 ms;
-// 24: +0.73 % / -0.07 %, +0.50 %, 2.52 ms; 16: +1.08 % / -0.10 %, +0.75 %, 2.49 ms.  32 keeps half the parity bound (1 %) as margin.
-constexpr double kHotPublications = 32.0;
+// Publications of a hot row per epoch and workgroup (rfm_fit_tuning.hot_publications).  A publication is not only five atomic requests
+// into the bins: with 48 of them every seventh row of config 2 publishes, i.e. nearly every second wavefront row step runs the publication
+// block for one of its four rows.  Measured at full size against the sequential oracle (tools/pub_margin.py; epoch 1 / 2 log-likelihood,
+// |w_i|, kernel) -- round 5: 48: +0.40 % / -0.04 %, +0.25 %, 2.67 ms; 32: +0.55 % / -0.05 %, +0.36 %, 2.58 ms; 24: +0.73 % / -0.07 %,
+// +0.50 %, 2.52 ms; 16: +1.08 % / -0.10 %, +0.75 %, 2.49 ms.  Round 6 (the bins drained by the epoch tail instead of behind every launch;
+// two runs each, profiles/r06_notes.md): 32: +0.52 % / -0.05 %, +0.35 %, 2.59 ms; 24: +0.70 % / -0.06 %, +0.49 %, 2.555 ms; 20: +0.84 % /
+// -0.08 %, +0.59 %, 2.545 ms.  24 since round 6: it keeps 0.3 of the parity bound (1 %) as margin; below it a
+// publication saved buys less and less time (the requests it saves are ~0.2 of 9.4 per update) for the same step in the log-likelihood.
+constexpr double kHotPublications = 24.0;
 // Table trainer quota on chip-filling launches: every (kTableQuotaFactor x row groups / 64)-th row -- the 446th on a full chip.  Round 4
 // found ranking quality a HUMP in it (denser: the trainer ran to the launch's end and cost the rows their quiet period, -3.8 points of
 // hit_rate@10 at every 250th row; sparser: -1.2 at the 600th).  Since round 5 a quota denser than the default makes the trainer stop by itself once 80 % of the
@@ -905,7 +908,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             scale[i] = n > damp_m ? (float)(damp_m / n) : 1.0f;
         }
         std::vector<int32_t> h_item(kMaxHot, 0), h_period(kMaxHot, 1);
-        // (BPR without features: 32, measured; WARP and the features kernels keep the 48 their parity figures were measured with)
+        // (BPR without features: 24, measured; WARP and the features kernels keep the 48 their parity figures were measured with)
         const double hot_pubs = T.hot_publications > 0 ? (double)T.hot_publications : (cfg->max_samples == 1 && !feat ? kHotPublications : 48.0);
         for (int s = 0; s < (use_hot ? n_hot : 0); ++s) {
             const int i = hot_order[s];
@@ -975,14 +978,22 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
     // call, and the device never waits for the host (a blocking read-back here idled it for a launch latency every eighth epoch).
     constexpr int kCheckEvery = 8;
     int epochs_launched = 0;
-    struct Probe {
-        unsigned int *host = nullptr;
-        ~Probe() { if (host) (void)hipHostFree(host); }
-    } probe;
+    // (the pinned buffer is kept per host thread and grown on demand: allocating and freeing pinned memory costs a call more than all of
+    //  its launches' gaps together)
+    struct Probe { unsigned int *host = nullptr; size_t words = 0; };
+    static thread_local Probe probe_cache;
+    Probe probe;
     hipEvent_t &probe_ev = ev[(size_t)2 * E];
     int probed = 0;                   // epochs covered by the copy in flight (0: none)
     if (cfg->check_finite && E > kCheckEvery) {
-        RFM_HIP(hipHostMalloc((void **)&probe.host, sizeof(unsigned int) * ((size_t)E + 16), hipHostMallocDefault));
+        if (probe_cache.words < (size_t)E + 16) {
+            if (probe_cache.host) (void)hipHostFree(probe_cache.host);
+            probe_cache.host = nullptr; probe_cache.words = 0;
+            const size_t words = std::max<size_t>(1024, (size_t)E + 16);
+            RFM_HIP(hipHostMalloc((void **)&probe_cache.host, sizeof(unsigned int) * words, hipHostMallocPortable));
+            probe_cache.words = words;
+        }
+        probe = probe_cache;
         RFM_HIP(hipEventCreateWithFlags(&probe_ev, hipEventDisableTiming));
     }
 

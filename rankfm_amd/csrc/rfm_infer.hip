@@ -429,6 +429,85 @@ __global__ void __launch_bounds__(256) scores_blockmax_kernel(const float *__res
     }
 }
 
+// The same block maxima with BOTH operands in registers (round 6; padded k <= 128).  scores_blockmax_kernel stages a 64 x 64 tile's
+// operands through LDS for every K-step of 32 and synchronises twice per step: with k = 64 a workgroup's whole life is two such steps, the
+// matrix cores wait for the loads of each (40 TF/s of the 157 TF/s fp32 peak).  Here a WAVEFRONT owns 32 users for
+// good -- its B operand, kp / 2 registers per lane, is loaded once -- and walks blocks of 32 items whose A operand (another kp / 2
+// registers) arrives from memory in 16-byte loads one block AHEAD of the one the matrix cores work on.  No LDS, no barrier.  What makes the
+// operands register-friendly is the freedom in which k goes to which half of the wavefront: v_mfma_f32_32x32x2_f32 takes, per step, k0 from
+// lanes 0 .. 31 and k1 from lanes 32 .. 63 -- any pairing of the k's into steps gives the same sum up to its order.  With k0 = s, k1 =
+// kp / 2 + s a lane needs kp / 2 CONTIGUOUS floats of its row of each operand.  (The order of the summation differs from the k-ordered
+// chain the candidates are re-scored with in select_blocks_kernel: the maxima only choose the candidate blocks, the ranking is the chain's --
+// and tests/test_gpu_api.py::test_matrix_free_and_matrix_recommend_paths_agree holds the two paths to each other.)
+// The four wavefronts of a workgroup walk the SAME item blocks for four neighbouring user blocks, so three of their four A loads hit L1.
+template <int KH>
+__global__ void __launch_bounds__(256) scores_blockmax_reg_kernel(const float *__restrict__ ueff, const float *__restrict__ veff,
+                                                                 const float *__restrict__ bias, const unsigned *__restrict__ mask, int n_slots,
+                                                                 int n_items, int n_words, float *__restrict__ bmax_val, int *__restrict__ bmax_idx) {
+    static_assert(KH % 4 == 0 && KH >= 16 && KH <= 64, "half the padded factor count, in 16-byte loads");
+    constexpr int kp = 2 * KH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int slot = (blockIdx.y * 4 + wave) * 32 + l31;
+    const bool slot_ok = slot < n_slots;
+    float b[KH];
+    {
+        const float4 *pb = reinterpret_cast<const float4 *>(ueff + (size_t)(slot_ok ? slot : 0) * kp + half * KH);
+#pragma unroll
+        for (int q = 0; q < KH / 4; ++q) {
+            const float4 v = slot_ok ? pb[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+        }
+    }
+    auto load_a = [&](int blk, float (&a)[KH]) {
+        const int it = blk * kBlk + l31;
+        const bool ok = blk < n_words && it < n_items;
+        const float4 *pa = reinterpret_cast<const float4 *>(veff + (size_t)(ok ? it : 0) * kp + half * KH);
+#pragma unroll
+        for (int q = 0; q < KH / 4; ++q) {
+            const float4 v = ok ? pa[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+        }
+    };
+    auto block = [&](int blk, const float (&a)[KH]) {
+        f32x16 acc = {0};
+#pragma unroll
+        for (int s2 = 0; s2 < KH; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2], acc, 0, 0, 0);
+        // accumulator register r of lane l: item row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the block, user column l & 31
+        const bool live = slot_ok && blk < n_words;
+        const unsigned seen = (live && mask) ? mask[(size_t)slot * n_words + blk] : 0u;
+        float bv = -INFINITY;
+        int bi = -1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int it = blk * kBlk + row;
+            if (live && it < n_items && !((seen >> row) & 1u)) {
+                const float v = acc[r] + bias[it];
+                if (v > -INFINITY && (bi < 0 || ranks_before(v, it, bv, bi))) { bv = v; bi = it; }
+            }
+        }
+        const float ov = __shfl_xor(bv, 32);
+        const int oi = __shfl_xor(bi, 32);
+        if (oi >= 0 && (bi < 0 || ranks_before(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+        if (live && lane < 32) {
+            bmax_val[(size_t)blk * n_slots + slot] = bv;
+            bmax_idx[(size_t)blk * n_slots + slot] = bi;
+        }
+    };
+    // item blocks blockIdx.x, blockIdx.x + gridDim.x, ...: two per trip, the second one's operand loading while the first is multiplied
+    float a0[KH], a1[KH];
+    int blk = blockIdx.x;
+    const int step = gridDim.x;
+    load_a(blk, a0);
+    for (; blk < n_words; blk += 2 * step) {
+        load_a(blk + step, a1);
+        block(blk, a0);
+        load_a(blk + 2 * step, a0);
+        if (blk + step < n_words) block(blk + step, a1);
+    }
+}
+
 __global__ void __launch_bounds__(256) select_blocks_kernel(const float *__restrict__ users, long long user_begin, int n_slots, int n_items, int kp,
                                                            const float *__restrict__ ueff, const float *__restrict__ veff,
                                                            const float *__restrict__ bias, const unsigned *__restrict__ mask, int n_words,
@@ -705,8 +784,21 @@ int rfm_recommend_device(const rfm_model_view *m, int64_t n_users, const float *
                     if (hipMemsetAsync(mask, 0, sizeof(unsigned) * (size_t)n_words * nu, stream) != hipSuccess) return RFM_ERR_HIP;
                     seen_mask_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, csr_off, csr_items, n_words, mask);
                 }
-                scores_blockmax_kernel<<<dim3((unsigned)((I + 63) / 64), (unsigned)((nu + 63) / 64)), dim3(256), 0, stream>>>(
-                    ueff_f, veff, bias, filter_previous ? mask : nullptr, (int)nu, m->n_items, kp, n_words, bmax_val, bmax_idx);
+                // block maxima: both operands in registers up to a padded k of 128 (scores_blockmax_reg_kernel), else staged through LDS.
+                // Item strips per user tile: enough workgroups for ~8 per CU, at least four item blocks each.
+                const unsigned user_tiles = (unsigned)((nu + 127) / 128);
+                const unsigned strips = (unsigned)std::max<long long>(1, std::min<long long>((n_words + 3) / 4, (2048 + user_tiles - 1) / user_tiles));
+                const dim3 rgrid(strips, user_tiles);
+                const unsigned *mk = filter_previous ? mask : nullptr;
+                switch (kp) {
+                case 32: scores_blockmax_reg_kernel<16><<<rgrid, dim3(256), 0, stream>>>(ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx); break;
+                case 64: scores_blockmax_reg_kernel<32><<<rgrid, dim3(256), 0, stream>>>(ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx); break;
+                case 96: scores_blockmax_reg_kernel<48><<<rgrid, dim3(256), 0, stream>>>(ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx); break;
+                case 128: scores_blockmax_reg_kernel<64><<<rgrid, dim3(256), 0, stream>>>(ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx); break;
+                default:
+                    scores_blockmax_kernel<<<dim3((unsigned)((I + 63) / 64), (unsigned)((nu + 63) / 64)), dim3(256), 0, stream>>>(
+                        ueff_f, veff, bias, mk, (int)nu, m->n_items, kp, n_words, bmax_val, bmax_idx);
+                }
                 select_blocks_kernel<<<dim3((unsigned)nu), dim3(256), 0, stream>>>(users, u0, (int)nu, m->n_items, kp, ueff_f, veff, bias,
                                                                                     filter_previous ? mask : nullptr, n_words, bmax_val,
                                                                                     bmax_idx, n_rec, rec);

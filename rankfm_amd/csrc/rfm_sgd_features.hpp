@@ -578,7 +578,14 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
         constexpr int SEGR = (kSegmentRows + G - 1) / G;
         int32_t seg_item[SEGR], seg_pos[SEGR];
         float seg_sw[SEGR];
-        float xu0 = 0.0f, xu1 = 0.0f;
+        // A = x_uf[u] . v_uf (:297-300), the user's projection into factor space: ONCE PER SEGMENT (round 6).  The user is the segment's, and
+        // the tables this workgroup reads are a copy that trails the trainer's by a refresh cycle anyway; projecting the user's tags again
+        // for every row was half of the row loop's 4096 LDS-operand multiply-adds (the other half, the item pair's difference, is the
+        // row's own).  What a row sees of v_uf is then up to a segment (<= 32 rows) old instead of a refresh cycle; with the tables frozen
+        // (the one-group parity mode of this loop) nothing changes at all.
+        float A[KPL];
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) A[k] = 0.0f;
         // the positive item's row, bias + step scale (one padded line), tags: fetched one row ahead
         struct Pos { float v[KPL]; float w, scale, x0, x1; } cur, nxt;
         auto fetch_pos = [&](int32_t it, Pos &p) {
@@ -664,11 +671,14 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
                 t = 0;
                 have = true;
                 step.load_ulist(lo, hi);
-                xu0 = xu1 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KPL; ++k) A[k] = 0.0f;
                 if (c.has_uf) {
+                    float xu0 = 0.0f, xu1 = 0.0f;
                     const float *x = c.x_uf + (size_t)u * c.n_uf;
                     if (sub < c.n_uf) xu0 = x[sub];
                     if (sub + G < c.n_uf) xu1 = x[sub + G];
+                    project_dense<KPL>(xu0, xu1, c.n_uf, uf_lane, A);
                 }
                 // the segment's rows in visiting order, held across the lanes (row t in lane t % G, register t / G)
 #pragma unroll
@@ -721,11 +731,9 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
                     if (sub < a.n_if) xj0 = x[sub];
                     if (sub + G < a.n_if) xj1 = x[sub + G];
                 }
-                // A = x_uf[u] . v_uf (:297-300), while the negative's row is on its way
-                float A[KPL], Bd[KPL];
+                float Bd[KPL];
 #pragma unroll
-                for (int k = 0; k < KPL; ++k) A[k] = Bd[k] = 0.0f;
-                if (a.has_uf) project_dense<KPL>(xu0, xu1, a.n_uf, uf_lane, A);
+                for (int k = 0; k < KPL; ++k) Bd[k] = 0.0f;
                 // pairwise utility (:239, :256-257 regrouped: both the utility and the gradients need the item-feature terms only as
                 // differences):  pu = (w_i - w_j) + (x_i - x_j).w_if + <v_u + A, v_i - v_j> + <(x_i - x_j).v_if, v_u>
                 float part = 0.0f;

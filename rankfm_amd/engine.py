@@ -15,6 +15,8 @@ WEIGHT_NAMES = ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")
 
 
 class DeviceSession:
+    RESERVE_EPOCHS = 64
+
     def __init__(self, interactions, sample_weight, csr_offsets, csr_items, x_uf, x_if, weights, *, alpha=0.01, beta=0.1,
                  learning_rate=0.1, learning_schedule="constant", learning_exponent=0.25, max_samples=1,
                  mode="hogwild", rng="counter", seed=1492, device=None, n_workgroups=0, rows_per_launch=0,
@@ -123,7 +125,10 @@ class DeviceSession:
     def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True, part=None, rng_epoch_offset=0):
         """train `epochs` epochs in place on the resident tensors; returns the per-epoch report (numpy arrays)"""
         cfg = self._config(epochs, epoch_begin, part, rng_epoch_offset)    # part = (k, n): only the k-th of n slices of each epoch's order
-        need = _hip.lib().rfm_fit_workspace_bytes(C.byref(cfg))
+        # (the workspace is sized for calls of up to RESERVE_EPOCHS epochs from the start: its per-epoch arrays are a few hundred bytes an
+        #  epoch, and a longer call than the first would otherwise re-allocate it and plan again)
+        size_cfg = self._config(max(int(epochs), self.RESERVE_EPOCHS), epoch_begin, part, rng_epoch_offset)
+        need = _hip.lib().rfm_fit_workspace_bytes(C.byref(size_cfg))
         if need == 0:
             _hip.raise_for_status(_hip.lib().rfm_fit_supported(C.byref(cfg)))
         if self._workspace is None or self._workspace.numel() < need:

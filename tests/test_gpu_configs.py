@@ -156,12 +156,22 @@ def test_config4_one_gpu_share_with_features_tracks_sequential_oracle(oracle):
     assert abs(r1["w_i"] - 1.0) <= 0.025 and abs(r1["v_u"] - 1.0) <= 0.01 and abs(r1["v_i"] - 1.0) <= 0.01, r1
     np.testing.assert_allclose(rep2["log_likelihood"], out2["ll64"], rtol=0.01)
     assert all(abs(r2[k] - 1.0) <= 0.015 for k in ("w_i", "v_u", "v_i")), r2
-    # the feature tables: |v_uf|, |v_if| within 10 %, |w_if| -- 32 numbers with a memory of ~170 steps -- within 15 % (VERDICT r04 item 2's
-    # bounds).  Measured in round 5 (three runs on two builds, profiles/r05_notes.md section 8): after the first epoch 1.044 ... 1.045 /
-    # 1.045 / 0.908, after the second 1.000 ... 1.002 / 0.923 ... 0.927 / 1.072 ... 1.086 (round 4's notes had 0.93 / 1.12 and 1.14 /
-    # 0.93 / 1.20 under the first quota rule); with the trainer's fixed quota they repeat to half a percent.
-    for r in (r1, r2):
-        assert all(abs(r[k] - 1.0) <= 0.10 for k in ("v_uf", "v_if")) and abs(r["w_if"] - 1.0) <= 0.15, r
+    # The feature tables, against the REFERENCE'S OWN run-to-run spread.  tests/golden/quality_tags_spread.npz holds
+    # eight runs of the reference itself on config 4 reduced 1 : 80 (same proportions, tags, learning rate) that differ in the order of the
+    # rows only: the tables are an exponential moving average of the last ~170 rows' gradient noise, and the reference's own |v_uf|, |v_if|,
+    # |w_if| move by 3.2 / 4.2 / 17 % (one sigma) after the first epoch and 1.8 / 4.6 / 12 % after the second from one order to the next
+    # (|w_i| 0.09 %, |v_u|, |v_i| 0.01 %) -- whatever the problem's size.  The engine's tables are held to max(2 %, 2 sigma_ref) of the
+    # oracle's: 6.4 / 8.4 / 34 % and 3.6 / 9.2 / 24 % (rounds 4 - 5 asserted 20 %, then 10 / 15 %, unanchored).  Measured in round 5 (three
+    # runs on two builds): after the first epoch 1.044 ... 1.045 / 1.045 / 0.908, after the second 1.000 ... 1.002 / 0.923 ... 0.927 /
+    # 1.072 ... 1.086; with the trainer's fixed quota they repeat to half a percent.
+    from conftest import load_golden
+    z = load_golden("quality", "tags_spread")
+    cols = [str(c) for c in z["c4r_columns"]]
+    rel_sigma = z["c4r_order_only"].std(axis=0, ddof=1) / np.abs(z["c4r_order_only"].mean(axis=0))
+    for epoch, r in ((1, r1), (2, r2)):
+        for k in ("v_uf", "v_if", "w_if"):
+            tol = max(0.02, 2.0 * float(rel_sigma[cols.index("e%d_norm_%s" % (epoch, k))]))
+            assert abs(r[k] - 1.0) <= tol, ("epoch %d |%s| gpu / oracle = %.4f, tolerance max(2 %%, 2 sigma_ref) = %.3f" % (epoch, k, r[k], tol), r)
     assert all(np.isfinite(g2[k]).all() for k in g2)
 
 

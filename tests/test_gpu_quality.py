@@ -49,6 +49,10 @@ def test_feature_model_matches_the_reference():
     z = load_golden("quality", "planted_tags")
     cols = list(z["columns"])
     ref = z["bpr"]
+    # (round 6) the reference's forty runs on the same five data sets -- eight visiting orders each from the initial weights of
+    # `np.random.seed(seed); fit(...)` -- instead of its five single runs: one run's hit rate moves by 1.6 points with the order alone
+    # (tests/golden/make_quality_tags_spread.py), so the mean of five carried +-0.7 point of its own against the 1-point bar
+    spread = load_golden("quality", "tags_spread")["tags_order_only"]              # [data seed, run, hit_rate | six norms]
     got = []
     for seed in range(5):
         d = synthetic.make_planted(seed=seed, n_users=3000, n_items=2000, mean_degree=100.0, n_tags=8)
@@ -64,14 +68,18 @@ def test_feature_model_matches_the_reference():
             np.random.seed(seed)
             m.fit(train, user_features=uf, item_features=itf, epochs=5)
             got.append([evaluation.hit_rate(m, test, k=10)] + [np.linalg.norm(getattr(m, k)) for k in ("v_u", "v_i", "w_i", "v_uf", "v_if", "w_if")])
-    got, want = np.mean(got, axis=0), ref[:, :7].mean(axis=0)
-    print("feature model: got", np.round(got, 4), "reference", np.round(want, 4))
+    got, want = np.mean(got, axis=0), spread.mean(axis=(0, 1))
+    # one run's sigma around its data seed's mean, relative: the reference's own run-to-run spread (order only)
+    sigma = np.sqrt(((spread - spread.mean(axis=1, keepdims=True)) ** 2).sum(axis=(0, 1)) / (spread.shape[0] * (spread.shape[1] - 1))) / np.abs(want)
+    print("feature model: got", np.round(got, 4), "reference (40 runs)", np.round(want, 4), "its five single runs", np.round(ref[:, :7].mean(axis=0), 4),
+          "reference's relative sigma of one run", np.round(sigma, 4))
     assert abs(got[0] - want[0]) <= 0.010, ("hit_rate@10", got[0], want[0])
-    np.testing.assert_allclose(got[1:3], want[1:3], rtol=0.025)                # |v_u|, |v_i|
-    np.testing.assert_allclose(got[3], want[3], rtol=0.025)                    # |w_i|
-    # the feature tables hold mostly gradient noise with a memory of ~1/(2 beta eta) rows: scale only
-    for k in (4, 5, 6):
-        assert 0.5 < got[k] / want[k] < 2.0, (cols[k], got[k], want[k])
+    # every norm within max(2 %, 2 sigma_ref) of the reference's mean: |v_u|, |v_i|, |w_i| 2 % (sigma_ref 0.4 - 0.6 %; rounds 4 - 5: 2.5 %);
+    # the tables -- mostly gradient noise with a memory of ~1 / (2 beta eta) rows, DESIGN.md section 5.3 -- 9 % / 8 % and, for the eight
+    # numbers of w_if, 2 sigma_ref = 70 % (rounds 4 - 5 allowed a factor 2 on all three, unanchored)
+    for k in range(1, 7):
+        tol = max(0.02, 2.0 * float(sigma[k]))
+        assert abs(got[k] / want[k] - 1.0) <= tol, (cols[k], got[k], want[k], tol)
 
 
 def test_default_sampler_holds_the_quality_bar_at_a_chip_filling_size():
@@ -120,6 +128,7 @@ def test_default_sampler_holds_the_quality_bar_at_a_chip_filling_size():
 # ---- the quality bar AT BASELINE config 2's shape: 100,000 users x 50,000 items, ~4.5 M training rows --------------
 C2_SHAPE = dict(U=100_000, I=50_000, E=5, SEEDS=5)
 C2_VARIANTS = {"bpr_k32": ("bpr", 32, 1), "bpr_k64": ("bpr", 64, 1), "warp_k32": ("warp", 32, 50),
+               "warp_k64": ("warp", 64, 50),        # (config 3's actual model: WARP, max_samples 50, k = 64 -- VERDICT r05 item 5)
                # config 4's kind of model at this size: 8 + 8 binary user / item tags that carry signal, learning rate 0.05 and ten epochs
                # (at the default 0.1 the REFERENCE ALGORITHM goes non-finite on tag features -- here as on config 4's, BASELINE.md
                # section 5 -- and at 0.03 five epochs learn too little to rank) -- the features kernels; three seeds
@@ -158,7 +167,7 @@ def c2_shape_jobs():
 def test_default_engine_holds_the_quality_bar_at_config2_shape(c2_shape_jobs, tag):
     """hit_rate@10 of the production default (uniform sampler, item damping, dynamic segment order) within 1.0 point of the sequential
     oracle with the reference's sampler (rankfm/_rankfm.pyx:250-253, evaluation.py:9-33), mean over FIVE seeds, at config 2's shape,
-    for BPR at k = 32 and k = 64, for WARP (max_samples 50, config 3's loss) at k = 32, and for a BPR model with 8 + 8 user / item tags
+    for BPR at k = 32 and k = 64, for WARP (max_samples 50, config 3's loss) at k = 32 and k = 64, and for a BPR model with 8 + 8 user / item tags
     (config 4's kind of model: the features kernels, three seeds); |v_u|, |v_i| within 2 %, |w_i| within 4 %."""
     from rankfm_amd import EngineOptions, RankFM, evaluation
     data, pending = c2_shape_jobs
@@ -261,7 +270,8 @@ def test_asynchrony_term_by_itself_at_config2_shape(c2_shape_jobs):
     when run sequentially, and ~16 k rows in flight cost ~1.5 - 2 points.  This test isolates the second: the engine against the sequential
     oracle run in the ENGINE'S order (rankfm_amd.order.epoch_positions; reference sampler, same initial weights), BPR k = 32, five
     seeds.  Asserted: the order bonus is what the notes say (the ordered oracle ranks 0.3 ... 2.0 points above the row-shuffled one), and
-    asynchronous execution + step damping cost at most 2.5 points against the ordered oracle (measured: see profiles/r05_notes.md) --
+    asynchronous execution + step damping cost at most 2.0 points against the ordered oracle (round 5 measured -1.87 at 16 k rows in
+    flight, bound 2.5; -1.63 since the BPR kernel runs 192 workgroups = 12 k rows in flight: the bound follows) --
     the bound the production concurrency plan (rfm_api.hip "launch geometry") is held to; the user-visible bar, 1.0 point against the
     reference's algorithm, is test_default_engine_holds_the_quality_bar_at_config2_shape."""
     from rankfm_amd import EngineOptions, RankFM, evaluation
@@ -288,7 +298,7 @@ def test_asynchrony_term_by_itself_at_config2_shape(c2_shape_jobs):
           % ({k: np.round(v, 4).tolist() for k, v in hits.items()}, mean, 100 * (mean["ordered oracle"] - mean["shuffled oracle"]),
              100 * (mean["engine"] - mean["ordered oracle"])))
     assert 0.003 <= mean["ordered oracle"] - mean["shuffled oracle"] <= 0.020, mean
-    assert mean["ordered oracle"] - mean["engine"] <= 0.025, mean
+    assert mean["ordered oracle"] - mean["engine"] <= 0.020, mean
 
 
 # ---- the table trainer's quota: no hump from x 0.5 to x 2 of the default -----------------------------------------
@@ -299,14 +309,13 @@ def _every_of(model, n_rows, epochs):
 
 
 def test_table_quota_sweep_on_the_reference_backed_feature_fixture():
-    """tests/golden/quality_planted_tags.npz (the REFERENCE's own fits): hit_rate@10 of the feature model at HALF and at TWICE the trainer's
-    default quota as well (`tune_table_every`; four engine runs per data seed and setting: twenty runs, whose mean still moves by +-0.3
-    point).  Measured over four sweeps (tools/feature_quality.py, profiles/r05_notes.md section 8; reference 0.4784): half the default's
-    spacing 0.4795 ... 0.4829, twice 0.4824 ... 0.4874 -- within a point; held to 1.5 (the default itself is held to 1.0 over forty runs by
-    test_feature_model_matches_the_reference)."""
+    """The REFERENCE's own fits (tests/golden/quality_tags_spread.npz: forty runs, mean pinned to +-0.25 point): hit_rate@10 of the feature
+    model at HALF and at TWICE the trainer's default quota as well (rfm_fit_tuning.table_every; four engine runs per data seed and setting:
+    twenty runs, whose mean still moves by +-0.3 point).  Measured over four sweeps in round 5 (tools/feature_quality.py): half the
+    default's spacing 0.4795 ... 0.4829, twice 0.4824 ... 0.4874.  Held to 1.0 point (round 5: 1.5, against the reference's five single
+    runs); the default itself is held to 1.0 over forty runs by test_feature_model_matches_the_reference."""
     from rankfm_amd import EngineOptions, RankFM, evaluation, synthetic
-    z = load_golden("quality", "planted_tags")
-    want = float(z["bpr"][:, 0].mean())
+    want = float(load_golden("quality", "tags_spread")["tags_order_only"][:, :, 0].mean())      # (the reference's forty runs: see above)
     data = []
     for seed in range(5):
         d = synthetic.make_planted(seed=seed, n_users=3000, n_items=2000, mean_degree=100.0, n_tags=8)
@@ -329,7 +338,7 @@ def test_table_quota_sweep_on_the_reference_backed_feature_fixture():
         got[name] = float(np.mean(hits))
     print("feature fixture, table quota sweep: default every %d-th row; hit_rate@10 %s, reference %.4f" % (every, got, want))
     for name, h in got.items():
-        assert abs(h - want) <= 0.015, (name, h, want)
+        assert abs(h - want) <= 0.010, (name, h, want)
 
 
 def test_table_quota_sweep_at_config2_shape_with_tags(c2_shape_jobs):
