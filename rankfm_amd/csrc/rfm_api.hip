@@ -283,6 +283,8 @@ constexpr double kHotPublications = 24.0;
 // rate 0.03 -- the tables' norms leave the oracle's (first epoch |w_if| +47 %, |v_if| +18 %, |w_i| +2.7 % against -9 %, +4.5 %, -1.1 %
 // at 2.4 x), so 2.4 x stays: the tables track the oracle's to 10 % there, and the sparse side (x 2) remains the open end of row a6.
 constexpr double kTableQuotaFactor = 2.4;
+// share of a launch's segments over which the trainer's quota is spread (SgdArgs::table_pace): where the default quota ends by itself
+constexpr float kTablePace = 0.65f;
 
 // (a user of degree d is cut into ceil(d / rows) <= d / rows + 1 segments)
 static size_t max_segments(int64_t n_rows, int n_users, int seg_rows) { return (size_t)n_users + (size_t)(n_rows / seg_rows) + 1; }
@@ -378,7 +380,7 @@ static int validate(const rfm_fit_config *c) {
     if (t.segment_rows < 0 || t.segment_rows > kSegmentRows || t.hot_publications < 0 || t.hot_publications > 65536 ||
         t.feature_waves < 0 || t.feature_waves > 16 || t.table_producers < 0 || t.table_producers > kFeatMaxProducers ||
         t.table_every < 0 || t.table_step_pct < 0 || t.table_step_pct > 400 || t.table_batch < 0 || t.table_batch > 256 || (t.table_batch & 3) ||
-        t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0)
+        t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0 || t.table_pace_pct < -1 || t.table_pace_pct > 100)
         return RFM_ERR_BAD_ARG;
     if (c->keep_layout != 0 && c->keep_layout != 1) return RFM_ERR_BAD_ARG;
     if (c->layout_token < 0 || (c->layout_token != 0 && c->plan_token <= 0)) return RFM_ERR_BAD_ARG;      // (a kept layout lives with its plan)
@@ -1044,6 +1046,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         a.table_quota = 0;
         a.table_step = T.table_step_pct > 0 ? (float)T.table_step_pct * 0.01f : 1.0f;
         a.table_quiet_from = 0.0f;
+        a.table_pace = 0.0f;
         // table trainer: steps to apply in a launch of `n_units` segments beside `rowloop_wgs` row-loop workgroups.  A row-loop workgroup
         // walks about as many rows per second as the trainer applies steps (profiles/r03_notes.md section 7), so a trainer that works
         // flat out for the length of the launch gets through rows / workgroups of them; measured on config 4's share with the split
@@ -1135,6 +1138,9 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
             a.tickets = tickets_of(window);
             if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, kTableQuotaFactor, &a.table_quiet_from);
+            // (the quota's batches spread over the first kTablePace of the launch: feat_step_producer; the opening launch above is unpaced --
+            //  its trainer is the slower side by design)
+            if (n_producers > 0) a.table_pace = T.table_pace_pct < 0 ? 0.0f : (T.table_pace_pct > 0 ? 0.01f * (float)T.table_pace_pct : kTablePace);
             launch(a, grid, stream);
         }
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));

@@ -90,6 +90,7 @@ struct SgdArgs {
     // derives from the launch's rows and geometry, not from when the row loops happen to finish (feat_tables_kernel)
     float table_step;                           // the trainer's step length relative to eta (tune_table_step_pct; 1 = the reference's)
     float table_quiet_from;                     // the trainer stops once this share of the launch's segments is handed out (0: never; see feat_table_trainer)
+    float table_pace;                           // the producers spread the quota's batches over this share of the launch's segments (0: as fast as they can; feat_step_producer)
     int64_t table_quota;
     unsigned long long *feat_clock;             // [4] wall-clock ticks: tables kernel begin | end | row-loop kernel begin | end (diagnostics)
     unsigned long long *sclk;                   // [4] workgroup 0 of the row-loop kernel: wall clock (100 MHz) at its start | end, shader cycle counter at its start | end

@@ -370,6 +370,23 @@ __device__ __forceinline__ void feat_step_producer(const SgdArgs &a, lds_float *
                 if (spin > kFeatSpinLimit) { atomicOr(a.error_flags, 8u); stop = 1; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
+            // Pacing (round 6, SgdArgs::table_pace): the trainer's quota is SPREAD over the first `table_pace` of the launch's segments instead
+            // of being worked off as fast as the producers can stage it.  Batch q of the launch (this producer's n-th) is produced once the
+            // row loops have been handed q / (batches of the quota) of that share -- the launch's ticket counter, read through an atomic: it
+            // is only ever written by memory-side atomics.  The default quota is done at ~0.64 of a launch by itself and barely waits here; a
+            // sparser one (tune `table_every`) used to be done within the first third and left the rows of two thirds of every launch
+            // without a table step (measured at config 2's shape with tags: twice the spacing -1.4 points of hit_rate@10 bunched, -0.9 when
+            // the same steps took 80 % of the launch: profiles/r06_notes.md).  The staged steps stay as fresh as before: a batch is scored
+            // when its turn has come, and the trainer applies it as soon as it is there.
+            if (!stop && a.table_pace > 0.0f && a.tickets != nullptr && a.pos_end > a.pos_begin) {
+                const unsigned quota_b = (unsigned)(((a.table_quota > (int64_t)gpb ? a.table_quota : (int64_t)gpb) + gpb - 1) / gpb);
+                const double need = (double)(n * (unsigned)NP + (unsigned)p) / (double)quota_b * (double)a.table_pace * (double)(a.pos_end - a.pos_begin);
+                for (unsigned spin = 0; spin <= kFeatSpinLimit; ++spin) {
+                    if ((double)__hip_atomic_fetch_add(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                    if (flag_load(flags + kFeatStop)) { stop = 1; break; }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+            }
             t_wait += wall_clock64() - t0;
             *s_stop_p = stop;
         }
