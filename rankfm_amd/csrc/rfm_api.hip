@@ -1140,7 +1140,12 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, kTableQuotaFactor, &a.table_quiet_from);
             // (the quota's batches spread over the first kTablePace of the launch: feat_step_producer; the opening launch above is unpaced --
             //  its trainer is the slower side by design)
-            if (n_producers > 0) a.table_pace = T.table_pace_pct < 0 ? 0.0f : (T.table_pace_pct > 0 ? 0.01f * (float)T.table_pace_pct : kTablePace);
+            // (only beside the pipelined row loop: the generic one strides the order statically and never touches the ticket counter)
+            // (and not in a fit's FIRST epoch: there the tables are leaving their initial values and every early step counts -- unpaced, the
+            //  quota is front-loaded; config 4's share, first epoch against the oracle: log-likelihood +0.55 % unpaced, +1.0 % paced)
+            const bool first_epoch = epoch == 0 && cfg->rng_epoch_offset == 0;
+            if (n_producers > 0 && feat_fast && a.tickets && (!first_epoch || T.table_pace_pct > 0))
+                a.table_pace = T.table_pace_pct < 0 ? 0.0f : (T.table_pace_pct > 0 ? 0.01f * (float)T.table_pace_pct : kTablePace);
             launch(a, grid, stream);
         }
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));

@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(256) scores_blockmax_kernel(const float *__res
 // chain the candidates are re-scored with in select_blocks_kernel: the maxima only choose the candidate blocks, the ranking is the chain's --
 // and tests/test_gpu_api.py::test_matrix_free_and_matrix_recommend_paths_agree holds the two paths to each other.)
 // The four wavefronts of a workgroup walk the SAME item blocks for four neighbouring user blocks, so three of their four A loads hit L1.
-template <int KH>
+template <int KH, bool MASK>
 __global__ void __launch_bounds__(256) scores_blockmax_reg_kernel(const float *__restrict__ ueff, const float *__restrict__ veff,
                                                                  const float *__restrict__ bias, const unsigned *__restrict__ mask, int n_slots,
                                                                  int n_items, int n_words, float *__restrict__ bmax_val, int *__restrict__ bmax_idx) {
@@ -450,61 +450,72 @@ __global__ void __launch_bounds__(256) scores_blockmax_reg_kernel(const float *_
     const int half = lane >> 5, l31 = lane & 31;
     const int slot = (blockIdx.y * 4 + wave) * 32 + l31;
     const bool slot_ok = slot < n_slots;
+    const int slot_c = slot_ok ? slot : n_slots - 1;        // (every load below is unconditional on a clamped address: no branch, so the
+    //                                                          compiler can wait for one block's operands while the next one's are in flight)
     float b[KH];
     {
-        const float4 *pb = reinterpret_cast<const float4 *>(ueff + (size_t)(slot_ok ? slot : 0) * kp + half * KH);
+        const float4 *pb = reinterpret_cast<const float4 *>(ueff + (size_t)slot_c * kp + half * KH);
 #pragma unroll
         for (int q = 0; q < KH / 4; ++q) {
-            const float4 v = slot_ok ? pb[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 v = pb[q];
             b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
         }
     }
-    auto load_a = [&](int blk, float (&a)[KH]) {
-        const int it = blk * kBlk + l31;
-        const bool ok = blk < n_words && it < n_items;
-        const float4 *pa = reinterpret_cast<const float4 *>(veff + (size_t)(ok ? it : 0) * kp + half * KH);
+    // the item biases ride in the product as one more k: A[row][kp] = bias (lanes 0 .. 31; 0 in the upper half), B[kp][col] = 1
+    const float b_one = 1.0f;
+    struct Operand { float a[KH]; float ab; unsigned seen; };
+    auto load_a = [&](int blk, Operand &o) {
+        const int bc = blk < n_words ? blk : n_words - 1;
+        const int it = bc * kBlk + l31 < n_items ? bc * kBlk + l31 : n_items - 1;
+        const float4 *pa = reinterpret_cast<const float4 *>(veff + (size_t)it * kp + half * KH);
 #pragma unroll
         for (int q = 0; q < KH / 4; ++q) {
-            const float4 v = ok ? pa[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            const float4 v = pa[q];
+            o.a[4 * q] = v.x; o.a[4 * q + 1] = v.y; o.a[4 * q + 2] = v.z; o.a[4 * q + 3] = v.w;
         }
+        const float bv = bias[it];
+        o.ab = half == 0 ? bv : 0.0f;
+        o.seen = 0u;
+        if constexpr (MASK) o.seen = mask[(size_t)slot_c * n_words + bc];
     };
-    auto block = [&](int blk, const float (&a)[KH]) {
+    auto block = [&](int blk, const Operand &o) {
         f32x16 acc = {0};
 #pragma unroll
-        for (int s2 = 0; s2 < KH; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2], b[s2], acc, 0, 0, 0);
-        // accumulator register r of lane l: item row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the block, user column l & 31
-        const bool live = slot_ok && blk < n_words;
-        const unsigned seen = (live && mask) ? mask[(size_t)slot * n_words + blk] : 0u;
+        for (int s2 = 0; s2 < KH; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[s2], b[s2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ab, b_one, acc, 0, 0, 0);
+        // accumulator register r of lane l: item row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the block, user column l & 31.  Rows ascend with
+        // r, so among equal scores the LATER register wins (ranks_before: the larger index first); selects, no branches.
         float bv = -INFINITY;
         int bi = -1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int it = blk * kBlk + row;
-            if (live && it < n_items && !((seen >> row) & 1u)) {
-                const float v = acc[r] + bias[it];
-                if (v > -INFINITY && (bi < 0 || ranks_before(v, it, bv, bi))) { bv = v; bi = it; }
-            }
+            const float v = acc[r];
+            const bool take = (it < n_items) & !((o.seen >> row) & 1u) & (v > -INFINITY) & (v >= bv);
+            bv = take ? v : bv;
+            bi = take ? it : bi;
         }
         const float ov = __shfl_xor(bv, 32);
         const int oi = __shfl_xor(bi, 32);
-        if (oi >= 0 && (bi < 0 || ranks_before(ov, oi, bv, bi))) { bv = ov; bi = oi; }
-        if (live && lane < 32) {
+        const bool other = (oi >= 0) & ((bi < 0) | (ov > bv) | ((ov == bv) & (oi > bi)));
+        bv = other ? ov : bv;
+        bi = other ? oi : bi;
+        if (slot_ok && lane < 32) {
             bmax_val[(size_t)blk * n_slots + slot] = bv;
             bmax_idx[(size_t)blk * n_slots + slot] = bi;
         }
     };
     // item blocks blockIdx.x, blockIdx.x + gridDim.x, ...: two per trip, the second one's operand loading while the first is multiplied
-    float a0[KH], a1[KH];
+    Operand o0, o1;
     int blk = blockIdx.x;
     const int step = gridDim.x;
-    load_a(blk, a0);
+    load_a(blk, o0);
     for (; blk < n_words; blk += 2 * step) {
-        load_a(blk + step, a1);
-        block(blk, a0);
-        load_a(blk + 2 * step, a0);
-        if (blk + step < n_words) block(blk + step, a1);
+        load_a(blk + step, o1);
+        block(blk, o0);
+        load_a(blk + 2 * step, o0);
+        if (blk + step < n_words) block(blk + step, o1);
     }
 }
 
@@ -790,11 +801,15 @@ int rfm_recommend_device(const rfm_model_view *m, int64_t n_users, const float *
                 const unsigned strips = (unsigned)std::max<long long>(1, std::min<long long>((n_words + 3) / 4, (2048 + user_tiles - 1) / user_tiles));
                 const dim3 rgrid(strips, user_tiles);
                 const unsigned *mk = filter_previous ? mask : nullptr;
+                auto reg = [&](auto with_mask, auto without_mask) {
+                    if (mk) hipLaunchKernelGGL(with_mask, rgrid, dim3(256), 0, stream, ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx);
+                    else hipLaunchKernelGGL(without_mask, rgrid, dim3(256), 0, stream, ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx);
+                };
                 switch (kp) {
-                case 32: scores_blockmax_reg_kernel<16><<<rgrid, dim3(256), 0, stream>>>(ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx); break;
-                case 64: scores_blockmax_reg_kernel<32><<<rgrid, dim3(256), 0, stream>>>(ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx); break;
-                case 96: scores_blockmax_reg_kernel<48><<<rgrid, dim3(256), 0, stream>>>(ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx); break;
-                case 128: scores_blockmax_reg_kernel<64><<<rgrid, dim3(256), 0, stream>>>(ueff_f, veff, bias, mk, (int)nu, m->n_items, n_words, bmax_val, bmax_idx); break;
+                case 32: reg(scores_blockmax_reg_kernel<16, true>, scores_blockmax_reg_kernel<16, false>); break;
+                case 64: reg(scores_blockmax_reg_kernel<32, true>, scores_blockmax_reg_kernel<32, false>); break;
+                case 96: reg(scores_blockmax_reg_kernel<48, true>, scores_blockmax_reg_kernel<48, false>); break;
+                case 128: reg(scores_blockmax_reg_kernel<64, true>, scores_blockmax_reg_kernel<64, false>); break;
                 default:
                     scores_blockmax_kernel<<<dim3((unsigned)((I + 63) / 64), (unsigned)((nu + 63) / 64)), dim3(256), 0, stream>>>(
                         ueff_f, veff, bias, mk, (int)nu, m->n_items, kp, n_words, bmax_val, bmax_idx);

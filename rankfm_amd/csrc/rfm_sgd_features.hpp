@@ -359,6 +359,8 @@ __device__ __forceinline__ void feat_step_producer(const SgdArgs &a, lds_float *
     unsigned draws_unused = 0;
     const unsigned long long t_begin = wall_clock64();
     unsigned long long t_wait = 0;
+    bool paced = true;                                   // (thread 0) still pacing: see below
+    constexpr unsigned kPaceGiveUp = 4096;               // polls (~1 us each) of an unmoving ticket counter before pacing is given up
     for (unsigned n = 0;; ++n) {
         const unsigned par = 0u, m = n;                  // (one slot per producer: see the trainer)
         if (threadIdx.x == 0) {
@@ -378,12 +380,20 @@ __device__ __forceinline__ void feat_step_producer(const SgdArgs &a, lds_float *
             // without a table step (measured at config 2's shape with tags: twice the spacing -1.4 points of hit_rate@10 bunched, -0.9 when
             // the same steps took 80 % of the launch: profiles/r06_notes.md).  The staged steps stay as fresh as before: a batch is scored
             // when its turn has come, and the trainer applies it as soon as it is there.
-            if (!stop && a.table_pace > 0.0f && a.tickets != nullptr && a.pos_end > a.pos_begin) {
+            // (The row loops are another KERNEL: if they are not running beside this one -- a profiler that serialises kernels, a device
+            //  without room -- the counter never moves; after kPaceGiveUp polls without seeing it move the producer stops pacing for the
+            //  rest of the launch: slower tables, still correct.  The host sets table_pace only for row loops that take tickets.)
+            if (!stop && paced && a.table_pace > 0.0f && a.tickets != nullptr && a.pos_end > a.pos_begin) {
                 const unsigned quota_b = (unsigned)(((a.table_quota > (int64_t)gpb ? a.table_quota : (int64_t)gpb) + gpb - 1) / gpb);
                 const double need = (double)(n * (unsigned)NP + (unsigned)p) / (double)quota_b * (double)a.table_pace * (double)(a.pos_end - a.pos_begin);
-                for (unsigned spin = 0; spin <= kFeatSpinLimit; ++spin) {
-                    if ((double)__hip_atomic_fetch_add(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                unsigned last = 0xFFFFFFFFu, idle = 0;
+                for (;;) {
+                    const unsigned handed = __hip_atomic_fetch_add(a.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((double)handed >= need) break;
                     if (flag_load(flags + kFeatStop)) { stop = 1; break; }
+                    idle = handed == last ? idle + 1 : 0;
+                    last = handed;
+                    if (idle > kPaceGiveUp) { paced = false; break; }
                     __builtin_amdgcn_s_sleep(16);
                 }
             }

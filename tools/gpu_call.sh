@@ -7,7 +7,7 @@ run_step() {
     local step=$1; shift
     case $step in
         suite)
-            ( time timeout 3000 python -m pytest tests -x -q -m gpu ) > $O/gpu_suite.log 2>&1; tail -8 $O/gpu_suite.log
+            ( time timeout 3000 python -m pytest tests -x -q -s -m gpu ) > $O/gpu_suite.log 2>&1; tail -8 $O/gpu_suite.log
             ( timeout 600 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; tail -4 $O/smoke.log ;;
         tests)
             local log=$O/tests_$(date +%H%M%S).log
@@ -22,6 +22,11 @@ run_step() {
             local tag=$1; shift
             RFM_PROFILE_PASSES="${RFM_PMC_PASSES:-FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum_TCC_EA0_RDREQ_sum_TCC_EA0_WRREQ_sum SQ_WAVE_CYCLES_SQ_WAIT_ANY_SQ_LDS_IDX_ACTIVE_SQ_INSTS_LDS_ATOMIC}" \
                 bash tools/profile_bench.sh $tag "$@" > $O/${tag}_pmc.log 2>&1; tail -3 $O/${tag}_pmc.log | cut -c1-600 ;;
+        prof)       # rocprofv3 --kernel-trace --stats of any python tool: prof <tag> <script> [args] -> gpurun_out/<tag>_kernel_stats.csv
+            local tag=$1; shift
+            mkdir -p $O/$tag
+            ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/$tag -o out --output-format csv -- python $OLDPWD/"$@" ) > $O/${tag}_prof.log 2>&1
+            cp $(find $O/$tag -name "*kernel_stats.csv" | head -1) $O/${tag}_kernel_stats.csv 2>/dev/null; head -12 $O/${tag}_kernel_stats.csv | cut -c1-200; tail -4 $O/${tag}_prof.log | cut -c1-300 ;;
         py)
             local script=$1; shift
             local log=$O/$(basename $script .py)_$(date +%H%M%S).log
