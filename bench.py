@@ -316,6 +316,7 @@ def main():
                                             syncs_per_epoch=(args.syncs_per_epoch if args.syncs_per_epoch == "auto" else int(args.syncs_per_epoch)),
                                             overlap=False if world == 1 else {"auto": "auto", "late": True, "blocking": False}[args.exchange], **session_kw)
         broadcast_from_rank0([trainer.shared.flat])
+        trainer.shared.record_waits = world > 1          # (time the waits for late reductions: `exposed_exchange_ms_per_epoch`)
         epoch = 0
         for _ in range(args.warmup):
             trainer.run_epoch(epoch)

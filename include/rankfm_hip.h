@@ -84,7 +84,7 @@ typedef struct rfm_fit_tuning {
                                       bit 8: the item damping scales an item's step only when it is the POSITIVE item (the round-3 rule),
                                       bit 9: chip-filling BPR launches keep the item factor rows row-major (no segment-major working copy) */
     int32_t segment_rows;          /* longest user segment, 1..32 (auto: 32) */
-    int32_t hot_publications;      /* publications of a hot row per epoch and workgroup (auto: 24 for BPR without features, else 48) */
+    int32_t hot_publications;      /* publications of a hot row per epoch and workgroup (auto: 24 for BPR, 48 for WARP) */
     int32_t feature_waves;         /* wavefronts per workgroup of the features kernels, 2..16 (auto: 16; the pipelined row loop 12) */
     int32_t table_producers;       /* features: step-producer workgroups feeding the table trainer, 1..16 (auto: 3 on a full chip, 2 / 1 on
                                       small launches) */

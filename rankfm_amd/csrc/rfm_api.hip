@@ -910,8 +910,9 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             scale[i] = n > damp_m ? (float)(damp_m / n) : 1.0f;
         }
         std::vector<int32_t> h_item(kMaxHot, 0), h_period(kMaxHot, 1);
-        // (BPR without features: 24, measured; WARP and the features kernels keep the 48 their parity figures were measured with)
-        const double hot_pubs = T.hot_publications > 0 ? (double)T.hot_publications : (cfg->max_samples == 1 && !feat ? kHotPublications : 48.0);
+        // (BPR, with or without features: 24, measured -- config 4's share 3.74 -> 3.63 ms; WARP keeps 48: its kernel does not notice
+        //  them, 8.74 / 8.77 / 8.76 ms at 32 / 24 / 16 on config 3: profiles/r06_notes.md)
+        const double hot_pubs = T.hot_publications > 0 ? (double)T.hot_publications : (cfg->max_samples == 1 ? kHotPublications : 48.0);
         for (int s = 0; s < (use_hot ? n_hot : 0); ++s) {
             const int i = hot_order[s];
             // publish about kHotPublications times per epoch and workgroup: ~3 % of the row's updates are pending chip-wide at any time

@@ -55,6 +55,7 @@ def take_user_shard(interactions, sample_weight, csr_offsets, csr_items, x_uf, v
 
 class SharedTables:
     """the replicated tables packed into one flat buffer; `views[name]` are the tensors handed to the engine"""
+    kMaxWaitEvents = 4096        # (exposed_exchange_ms: event pairs kept between two readings)
 
     def __init__(self, tables, device):
         shapes = {k: tuple(tables[k].shape) for k in SHARED_NAMES}
@@ -274,7 +275,8 @@ class SharedTables:
         if getattr(self, "_late_own", None) is None:
             self._late_own, self._late_sum = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
             self._late_work, self._late_meta = None, None
-            self.late_wait_events = []                     # (CUDA) event pairs around every wait for a reduction: the EXPOSED exchange time
+            self.late_wait_events = []                     # (CUDA) event pairs around the waits for reductions: the EXPOSED exchange time --
+            #                                                recorded only while `record_waits` is set (bench.py), at most kMaxWaitEvents of them
         t = self.tail
         log_rho_v = torch.log1p(-torch.clamp(lr * c_v * self._mean_vu2, max=0.5))
         log_rho_w = float(np.log1p(-min(lr * c_w, 0.5)))
@@ -290,8 +292,9 @@ class SharedTables:
         torch.sub(self.flat, self.start, out=self._late_tmp)                 # this window's own delta (tail: its curvature terms)
         flag = self._late_apply()                                            # the PREVIOUS window's correction (waits for its reduction)
         self.tail.zero_()                                                    # (the tail belongs to the exchange, not to the tables)
-        # a peer failed in the previous window and has left: no further collective is launched (the caller raises).  Reading the flag
-        # is a 4-byte device read-back; the reduction it belongs to was launched a whole window ago.
+        # a peer failed in the previous window and has LEFT: no further collective may be launched (it would never complete), so the verdict
+        # is needed on the host before the next all-reduce is submitted -- a 4-byte read-back that waits for this window's SGD (ADVICE r05:
+        # it costs the launch-ahead of short windows; the alternative, a failed rank that stays for one more collective, was not built)
         if float(flag) > 0:
             return flag
         self._late_own, self._late_tmp = self._late_tmp, self._late_own
@@ -309,7 +312,7 @@ class SharedTables:
         if getattr(self, "_late_work", None) is None:
             return zero
         if self._late_work is not True:
-            if self.flat.is_cuda:
+            if self.flat.is_cuda and getattr(self, "record_waits", False) and len(self.late_wait_events) < self.kMaxWaitEvents:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self._late_work.wait()
