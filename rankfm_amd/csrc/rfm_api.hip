@@ -273,6 +273,13 @@ constexpr int kMaxHot = 64;                      // hot-row accumulator slots pe
 // -0.08 %, +0.59 %, 2.545 ms.  24 since round 6: it keeps 0.3 of the parity bound (1 %) as margin; below it a
 // publication saved buys less and less time (the requests it saves are ~0.2 of 9.4 per update) for the same step in the log-likelihood.
 constexpr double kHotPublications = 24.0;
+// Row steps between two sweeps of a workgroup's bin lines (BPR segments kernel; SgdArgs::hot_sweep_every).  A sweep is sixteen returning
+// exchanges and an add per line: at one sweep per row step 1.8 M of a config-2 launch's 47 M memory-side requests.  What a publication
+// waits in a bin (~4 us at every step) is small beside what it waited in LDS before (~50 us at 24 publications per epoch), so sweeping
+// less often buys more time per unit of log-likelihood than publishing less often.  Measured (round 6, one box, interleaved sessions;
+// first-epoch log-likelihood against the oracle at full size, tools/pub_margin.py): every step 2.551 ms / +0.70 %; every 2nd 2.513;
+// every 4th 2.505 / +0.81 % (with 32 publications 2.532 / +0.65 %); every 8th 2.495 / +1.04 % -- over the 1 % bound.
+constexpr int kHotSweepEvery = 4;
 // Table trainer quota on chip-filling launches: every (kTableQuotaFactor x row groups / 64)-th row -- the 446th on a full chip.  Round 4
 // found ranking quality a HUMP in it (denser: the trainer ran to the launch's end and cost the rows their quiet period, -3.8 points of
 // hit_rate@10 at every 250th row; sparser: -1.2 at the 600th).  Since round 5 a quota denser than the default makes the trainer stop by itself once 80 % of the
@@ -380,7 +387,7 @@ static int validate(const rfm_fit_config *c) {
     if (t.segment_rows < 0 || t.segment_rows > kSegmentRows || t.hot_publications < 0 || t.hot_publications > 65536 ||
         t.feature_waves < 0 || t.feature_waves > 16 || t.table_producers < 0 || t.table_producers > kFeatMaxProducers ||
         t.table_every < 0 || t.table_step_pct < 0 || t.table_step_pct > 400 || t.table_batch < 0 || t.table_batch > 256 || (t.table_batch & 3) ||
-        t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0 || t.table_pace_pct < -1 || t.table_pace_pct > 100)
+        t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0 || t.table_pace_pct < -1 || t.table_pace_pct > 100 || t.hot_sweep_every < 0 || t.hot_sweep_every > 64)
         return RFM_ERR_BAD_ARG;
     if (c->keep_layout != 0 && c->keep_layout != 1) return RFM_ERR_BAD_ARG;
     if (c->layout_token < 0 || (c->layout_token != 0 && c->plan_token <= 0)) return RFM_ERR_BAD_ARG;      // (a kept layout lives with its plan)
@@ -1034,6 +1041,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         a.hot_item = ws.hot_item; a.hot_period = ws.hot_period; a.n_hot = use_hot ? n_hot : 0;
         a.hot_bins_v = ws.hot_bins_v; a.hot_bins_w = ws.hot_bins_w; a.sw_max_bits = ws.sw_max_bits;
         // (sweeping workgroups: all of them, or the row-loop workgroups of the features kernel)
+        a.hot_sweep_every = T.hot_sweep_every > 0 ? T.hot_sweep_every : kHotSweepEvery;
         a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * (grid - (n_producers > 0 ? 1 + n_producers : 0)) ? 1 : 0;   // see SgdArgs::hot_bins_v
         a.launch_index = 0;
         a.block_threads = waves_per_block * 64;

@@ -67,6 +67,7 @@ struct SgdArgs {
     float *hot_bins_v;                          // [kHotBins, n_hot, F]   (hot_bin_v)
     float *hot_bins_w;                          // [kHotBins, n_hot]      (hot_bin_w)
     int32_t hot_direct;
+    int32_t hot_sweep_every;                    // a wavefront's sweeping turn comes every (wavefronts x this many) iterations (BPR segments kernel)
     const unsigned int *sw_max_bits;            // bits of max |sample_weight| (plan): range of the fixed-point hot sums
     uint32_t launch_index;                      // which launch of the epoch this is (keys the step producers' row sample)
     // features kernel: the step producers hand their batches to the table trainer through `feat_ring` ([2 * n_producers] slots of

@@ -104,6 +104,9 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_segments_kernel(const Sg
 #pragma unroll
     for (int k = 0; k < KPL; ++k) vu[k] = vu0[k] = 0.0f;
 
+    // (sweeping turns, HOT: wavefront w of the workgroup sweeps in iterations w x every, w x every + wavefronts x every, ...)
+    const int sweep_mod = (int)(blockDim.x >> 6) * (a.hot_sweep_every > 0 ? a.hot_sweep_every : 1);
+    const int sweep_at = (int)(threadIdx.x >> 6) * (a.hot_sweep_every > 0 ? a.hot_sweep_every : 1);
     for (int iter = 0;; ++iter) {
         if (!__any(active)) break;
         if constexpr (HOT) {
@@ -116,8 +119,7 @@ __global__ void __launch_bounds__(HOT ? 1024 : 256) sgd_segments_kernel(const Sg
             // system-scope loads, then subtracting what was read -- diverged: a bin that reads as zero is not written by its sweeper,
             // its line stays in the sweeper's L2, and the memory-side atomics of the publishers in the other XCDs never invalidate
             // it.  profiles/r04_notes.md.)
-            const int n_waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
-            if (!a.hot_direct && iter % n_waves == wave) {
+            if (!a.hot_direct && iter % sweep_mod == sweep_at) {
                 RFM_COLD_ARGS(c)                                 // (the rarely executed parts read their arguments afresh: cold_args)
                 for (int line = blockIdx.x; line < hot_lines(c); line += gridDim.x) hot_sweep_line(c, line);
             }

@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pubs", default="48,32,24")
+    ap.add_argument("--tune", default="", help="further overrides applied to every run: 'hot_sweep_every=4'")
     ap.add_argument("--runs", type=int, default=2)
     ap.add_argument("--flags", type=int, default=0)
     a = ap.parse_args()
@@ -34,7 +35,9 @@ def main():
     oo = oout = None
     for pub in [int(p) for p in a.pubs.split(",")]:
         for run in range(a.runs):
-            sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=1, seed=1492, tune={"hot_publications": pub},
+            tune = {"hot_publications": pub}
+            tune.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tune.split(",") if kv})
+            sess = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w, max_samples=1, seed=1492, tune=tune,
                                  debug_flags=a.flags)
             rep = sess.run(epochs=2)
             g = sess.weights_to_host()
