@@ -97,7 +97,7 @@ typedef struct rfm_fit_tuning {
                                       the tables, DESIGN.md 3.3 */
     int32_t hot_sweep_every;       /* BPR segments kernel: a workgroup's hot-row bin lines are swept every this many row steps (auto: see
                                       rfm_api.hip kHotSweepEvery) */
-    int32_t reserved;              /* 0 */
+    int32_t hot_slots;             /* most hot item rows a workgroup accumulates in LDS, up to 128 (auto: 64) */
     int32_t table_pace_pct;        /* features: the trainer's quota is spread over this percentage of a launch's segments (auto: 65 -- where the default
                                       quota ends by itself; -1: unpaced, as fast as the producers stage it: rounds 3 - 5) */
 } rfm_fit_tuning;

@@ -25,7 +25,7 @@ class FitTuning(C.Structure):
     _fields_ = [
         ("n_workgroups", C.c_int32), ("rows_per_launch", C.c_int32), ("debug_shape", C.c_int32), ("debug_flags", C.c_int32),
         ("segment_rows", C.c_int32), ("hot_publications", C.c_int32), ("feature_waves", C.c_int32), ("table_producers", C.c_int32),
-        ("table_every", C.c_int32), ("table_step_pct", C.c_int32), ("table_batch", C.c_int32), ("hot_sweep_every", C.c_int32), ("reserved", C.c_int32), ("table_pace_pct", C.c_int32),
+        ("table_every", C.c_int32), ("table_step_pct", C.c_int32), ("table_batch", C.c_int32), ("hot_sweep_every", C.c_int32), ("hot_slots", C.c_int32), ("table_pace_pct", C.c_int32),
     ]
 
 
@@ -48,7 +48,7 @@ class FitConfig(C.Structure):
 
 
 #: names of the geometry overrides of rfm_fit_tuning (0 = automatic); EngineOptions.tune / DeviceSession(tune=...) carry them
-TUNE_FIELDS = ("segment_rows", "hot_publications", "feature_waves", "table_producers", "table_every", "table_step_pct", "table_batch", "table_pace_pct", "hot_sweep_every")
+TUNE_FIELDS = ("segment_rows", "hot_publications", "feature_waves", "table_producers", "table_every", "table_step_pct", "table_batch", "table_pace_pct", "hot_sweep_every", "hot_slots")
 
 
 def tune_kwargs(tune):

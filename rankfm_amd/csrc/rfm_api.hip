@@ -263,7 +263,8 @@ static rfm_fit_tuning tuning_of(const rfm_fit_config *c) {
     return t;
 }
 
-constexpr int kMaxHot = 64;                      // hot-row accumulator slots per workgroup (LDS: kMaxHot * (F + 2) floats)
+constexpr int kMaxHot = 128;                     // most hot-row accumulator slots per workgroup a plan can have (LDS: slots * (F + 2) floats)
+constexpr int kHotSlots = 64;                    // ... and what a plan takes unless told otherwise (rfm_fit_tuning.hot_slots)
 // Publications of a hot row per epoch and workgroup (rfm_fit_tuning.hot_publications).  A publication is not only five atomic requests
 // into the bins: with 48 of them every seventh row of config 2 publishes, i.e. nearly every second wavefront row step runs the publication
 // block for one of its four rows.  Measured at full size against the sequential oracle (tools/pub_margin.py; epoch 1 / 2 log-likelihood,
@@ -387,7 +388,7 @@ static int validate(const rfm_fit_config *c) {
     if (t.segment_rows < 0 || t.segment_rows > kSegmentRows || t.hot_publications < 0 || t.hot_publications > 65536 ||
         t.feature_waves < 0 || t.feature_waves > 16 || t.table_producers < 0 || t.table_producers > kFeatMaxProducers ||
         t.table_every < 0 || t.table_step_pct < 0 || t.table_step_pct > 400 || t.table_batch < 0 || t.table_batch > 256 || (t.table_batch & 3) ||
-        t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0 || t.table_pace_pct < -1 || t.table_pace_pct > 100 || t.hot_sweep_every < 0 || t.hot_sweep_every > 64)
+        t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0 || t.table_pace_pct < -1 || t.table_pace_pct > 100 || t.hot_sweep_every < 0 || t.hot_sweep_every > 64 || t.hot_slots < 0 || t.hot_slots > 128)
         return RFM_ERR_BAD_ARG;
     if (c->keep_layout != 0 && c->keep_layout != 1) return RFM_ERR_BAD_ARG;
     if (c->layout_token < 0 || (c->layout_token != 0 && c->plan_token <= 0)) return RFM_ERR_BAD_ARG;      // (a kept layout lives with its plan)
@@ -804,7 +805,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             if ((double)item_count[i] * g0 / (double)N >= kHotMin) hot_order.push_back(i);
         std::sort(hot_order.begin(), hot_order.end(), [&](int x, int y) { return item_count[x] > item_count[y] || (item_count[x] == item_count[y] && x < y); });
         // LDS budget of the accumulators: 48 KiB per workgroup
-        const int max_hot = std::min(kMaxHot, 12288 / (cfg->n_factors + 2));
+        const int max_hot = std::min(T.hot_slots > 0 ? std::min(T.hot_slots, kMaxHot) : kHotSlots, 12288 / (cfg->n_factors + 2));
         if ((int)hot_order.size() > max_hot) hot_order.resize(max_hot > 0 ? max_hot : 0);
         n_hot = (int)hot_order.size();
     }

@@ -18,10 +18,9 @@ run_step() {
         stats)
             local tag=$1; shift
             RFM_PROFILE_PASSES="stats" bash tools/profile_bench.sh $tag "$@" > $O/${tag}_profile.log 2>&1; tail -6 $O/${tag}_profile.log | cut -c1-400 ;;
-        pmc)
+        pmc)        # the kernel statistics AND the separate --pmc passes of tools/profile_bench.sh (RFM_PMC_PASSES="FETCH_SIZE WRITE_SIZE" = a subset)
             local tag=$1; shift
-            RFM_PROFILE_PASSES="${RFM_PMC_PASSES:-FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum_TCC_EA0_RDREQ_sum_TCC_EA0_WRREQ_sum SQ_WAVE_CYCLES_SQ_WAIT_ANY_SQ_LDS_IDX_ACTIVE_SQ_INSTS_LDS_ATOMIC}" \
-                bash tools/profile_bench.sh $tag "$@" > $O/${tag}_pmc.log 2>&1; tail -3 $O/${tag}_pmc.log | cut -c1-600 ;;
+            RFM_PROFILE_PASSES="${RFM_PMC_PASSES:-all}" bash tools/profile_bench.sh $tag "$@" > $O/${tag}_pmc.log 2>&1; tail -3 $O/${tag}_pmc.log | cut -c1-600 ;;
         prof)       # rocprofv3 --kernel-trace --stats of any python tool: prof <tag> <script> [args] -> gpurun_out/<tag>_kernel_stats.csv
             local tag=$1; shift
             mkdir -p $O/$tag
