@@ -659,6 +659,8 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
             sp = __shfl(first, lane_base);
             active = active && sp >= 0;
         }
+        // (sweeping turns: wavefront w sweeps in iterations w x every, w x every + wavefronts x every, ...: SgdArgs::hot_sweep_every)
+        const int sweep_mod = n_waves * (a.hot_sweep_every > 0 ? a.hot_sweep_every : 1), sweep_at = wave * (a.hot_sweep_every > 0 ? a.hot_sweep_every : 1);
         for (int iter = 0; __any(active); ++iter) {
             // Every wavefront keeps a slice of the workgroup's copy fresh, a part of it per row: the loads are issued here and land in
             // LDS at the END of the row, so that their latency (system-scope loads go to memory) is the row's, not an extra round
@@ -678,7 +680,7 @@ __global__ void __launch_bounds__(THREADS) sgd_features_fast_kernel(const SgdArg
             }
             // bin sweeping duty (SgdArgs::hot_bins_v).  The lines are owned by the ROW-LOOP workgroups only: the trainer and the producers
             // never come here, and a line nobody sweeps -- the first lines are the hottest items' -- would stay unpublished all launch
-            if (n_hot > 0 && !a.hot_direct && iter % n_waves == wave) {
+            if (n_hot > 0 && !a.hot_direct && iter % sweep_mod == sweep_at) {
                 const SgdArgs c = cold_args();                           // (the rarely executed parts read their arguments afresh: cold_args)
                 for (int line = (int)blockIdx.x - first_regular; line < hot_lines(c); line += n_regular) hot_sweep_line(c, line);
             }
