@@ -280,3 +280,33 @@ def test_kept_engine_layout_loses_no_update_at_config2_scale(c2_problem):
                           alpha=0.0, beta=0.0, max_samples=1, seed=1492, hogwild_damping=1e9)
     rep_f = fresh.run(epochs=1, epoch_begin=e)
     assert rep_f["log_likelihood"][0] == pytest.approx(rep_k["log_likelihood"][0], rel=2e-3)
+
+
+def test_kept_engine_layout_with_a_feature_model_trains_the_same_model():
+    """keep_layout on a model with features (padded biases + hot-row bins kept; the feature tables themselves are never re-laid): the
+    engine's Hogwild run is not bit-reproducible, so a kept session is held to a converting session statistically -- five one-epoch calls
+    each from the same weights: log-likelihood per epoch within 1.5 %, the row norms within 1 % -- and its exported weights must be what
+    `predict` serves."""
+    from rankfm_amd import synthetic
+    from rankfm_amd.engine import DeviceSession
+    U, I, F, P, Q = 6000, 4000, 32, 8, 8
+    pairs, csr = synthetic.make_interactions(U, I, 400_000, seed=5)
+    sw = np.ones(len(pairs), np.float32)
+    w0 = synthetic.init_weights(U, I, F, P, Q, seed=2)
+    x_uf, x_if = synthetic.make_features(U, P, 3), synthetic.make_features(I, Q, 4)
+    lls = {}
+    sessions = {}
+    for keep in (False, True):
+        s = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w0, seed=3, learning_rate=0.03, keep_layout=keep)
+        lls[keep] = np.concatenate([s.run(epochs=1, epoch_begin=e)["log_likelihood"] for e in range(5)])
+        assert (s._layout_token != 0) == keep
+        sessions[keep] = s
+    np.testing.assert_allclose(lls[True], lls[False], rtol=0.015)
+    a, b = sessions[False].weights_to_host(), sessions[True].weights_to_host()
+    for k in ("w_i", "v_u", "v_i"):
+        assert abs(np.linalg.norm(a[k]) / np.linalg.norm(b[k]) - 1.0) <= 0.01, k
+    assert all(np.isfinite(b[k]).all() for k in b)
+    idx = np.stack([np.arange(64) % U, np.arange(64) % I], 1).astype(np.float32)
+    from rankfm_amd._rankfm import _predict
+    np.testing.assert_allclose(sessions[True].predict(idx), _predict(idx, x_uf, x_if, b["w_i"], b["w_if"], b["v_u"], b["v_i"], b["v_uf"], b["v_if"]),
+                               rtol=1e-6, atol=1e-6)

@@ -56,6 +56,15 @@ def test_the_pipelined_feature_row_loop_fits_three_wavefronts_per_simd(kernels):
         assert r["vgpr_spill"] == 0, r
 
 
+def test_the_serving_kernels_of_round_6_do_not_spill(kernels):
+    # _recommend's product with both operands in registers (padded k = 32 ... 128, with and without the observed-items mask) and the
+    # one-wavefront-per-user selection: all of their state is registers by design
+    for r in pick(kernels, "scores_blockmax_reg_kernel<"):
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["lds_static"] == 0, r
+    for r in pick(kernels, "select_blocks_wave_kernel<"):
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, r
+
+
 def _memory_ops(lib, symbol_part):
     """vector-memory instructions and vmcnt waits of one kernel of the built library, in program order (llvm-objdump on the code object)"""
     import re
