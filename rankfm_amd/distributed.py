@@ -56,6 +56,19 @@ def take_user_shard(interactions, sample_weight, csr_offsets, csr_items, x_uf, v
 class SharedTables:
     """the replicated tables packed into one flat buffer; `views[name]` are the tensors handed to the engine"""
     kMaxWaitEvents = 4096        # (exposed_exchange_ms: event pairs kept between two readings)
+    # How the dense FEATURE tables (v_if, w_if, v_uf) are merged (round 6).  They are not sums of small steps: a rank's table trainer
+    # REPLACES them within ~170 of its steps by an exponential moving average of recent gradient noise around a slowly moving signal.
+    #   "one"   (default) a blocking exchange takes the tables of ONE rank -- the ranks take turns -- which are a sample of exactly the
+    #           process a single GPU's tables are; the late merge leaves every rank its own tables between exchanges (a late correction of a
+    #           quantity that forgets within a fraction of a window only perturbs it) and the closing broadcast hands out rank 0's;
+    #   "mean"  (rounds 1 - 5) the average over the ranks: the noise part shrinks by sqrt(ranks) -- config 4 at its own size, eight shards:
+    #           |v_if| 0.38, |w_if| 0.42 of a single GPU's -- and with the late merge at 24 windows per epoch the corrected tables destabilise
+    #           the fit (norms x 10^3 after two epochs; tests/test_gpu_configs.py, tools/merge_c4_scan.py).
+    table_merge = "one"
+    TABLE_NAMES = ("v_if", "w_if", "v_uf")
+
+    def _table_regions(self):
+        return [(self._starts[k], self._starts[k] + self._sizes[k]) for k in self.TABLE_NAMES]
 
     def __init__(self, tables, device):
         shapes = {k: tuple(tables[k].shape) for k in SHARED_NAMES}
@@ -147,9 +160,13 @@ class SharedTables:
         self._curvature = (float(learning_rate), float(self.CURVATURE_FACTORS if c_factors is None else c_factors),
                            float(self.CURVATURE_BIASES if c_biases is None else c_biases))
         self._world = int(world_size)
-        self.merge_scale = torch.full_like(self.flat, 1.0 / world_size) if world_size > 1 else None      # (feature tables: the average)
+        self.merge_scale = torch.full_like(self.flat, 1.0 / world_size) if world_size > 1 else None      # (feature tables with table_merge "mean": the average)
         if self.merge_scale is not None:
             self.merge_scale[self._tail_at:] = 1.0                                                       # (the tail comes back as the plain sum)
+            if self.table_merge == "one":                                                                # (ONE rank's tables come back: the sum of one delta and zeros)
+                for a, b in self._table_regions():
+                    self.merge_scale[a:b] = 1.0
+        self._n_exchanges = 0
         # exchange_fused: per-item totals over all ranks (static: summed once, here) and the mean |v_u|^2 every rank starts from
         self._n_total = self._n_local.clone()
         if dist.is_available() and dist.is_initialized() and world_size > 1:
@@ -228,6 +245,11 @@ class SharedTables:
                 _hip.raise_for_status(_hip.lib().rfm_delta_begin(self.flat.data_ptr(), self.start.data_ptr(), n, stream))
         else:
             self.flat.sub_(self.start)
+        if world > 1 and self.table_merge == "one":          # the feature tables of the rank whose turn it is
+            if (dist.get_rank(group) if group is not None else dist.get_rank()) != self._n_exchanges % world:
+                for a, b in self._table_regions():
+                    self.flat[a:b].zero_()
+        self._n_exchanges += 1
         if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         t_v, t_w = t[:n_items].to(torch.float64), t[n_items:2 * n_items].to(torch.float64)
@@ -290,6 +312,9 @@ class SharedTables:
         if getattr(self, "_late_tmp", None) is None:
             self._late_tmp = torch.zeros_like(self.flat)
         torch.sub(self.flat, self.start, out=self._late_tmp)                 # this window's own delta (tail: its curvature terms)
+        if self.table_merge == "one":                                        # (the feature tables stay the rank's own until finish_late)
+            for a, b in self._table_regions():
+                self._late_tmp[a:b].zero_()
         flag = self._late_apply()                                            # the PREVIOUS window's correction (waits for its reduction)
         self.tail.zero_()                                                    # (the tail belongs to the exchange, not to the tables)
         # a peer failed in the previous window and has LEFT: no further collective may be launched (it would never complete), so the verdict
@@ -665,7 +690,8 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
                           eta_fn=eta_of, overlap=overlap), sess
 
 
-def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per_epoch=1, seed=1492, c_factors=None, c_biases=None, late=False, **session_kw):
+def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per_epoch=1, seed=1492, c_factors=None, c_biases=None, late=False,
+                                table_merge="one", **session_kw):
     """What `world` ranks would compute, on ONE GPU and in one process: `world` user shards, each trained by the REAL engine (its own
     DeviceSession, its own copy of the item-side tables, the concurrency plan a rank of that size gets), merged after every exchange
     window exactly like ShardedTrainer / SharedTables.exchange_fused merge the ranks -- curvature rule, rho from the mean |v_u|^2 of
@@ -697,6 +723,7 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
     master = ref.flat[:T].clone()
     scale = torch.full((T,), 1.0 / world, dtype=torch.float32, device=device)
     pending = None                # (late) the window whose "reduction" is in flight: (scale, total, own deltas, mean |v_u|^2 it reports)
+    n_windows_done = 0
 
     def apply_pending():
         nonlocal mean_vu2
@@ -725,6 +752,11 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
                     sum_vu2 = sum_vu2 + torch.linalg.vector_norm(sess.weights["v_u"], dtype=torch.float64) ** 2
                     users += int(sess.weights["v_u"].shape[0])
                 d = tr.shared.flat[:T] - before
+                if table_merge == "one":          # blocking: the feature tables of ONE shard per window (the shards take turns), not the mean
+                    for name in ("v_if", "w_if", "v_uf"):     # of all; late: every shard keeps its own until the end (SharedTables.table_merge)
+                        a0 = ref._starts[name]
+                        if late or r != n_windows_done % world:
+                            d[a0:a0 + ref._sizes[name]] = 0.0
                 total += d
                 if late:
                     own.append(d)
@@ -737,6 +769,11 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
             scale[a:a + ref._sizes["v_i"]].view(n_items, F).copy_(sv.to(torch.float32)[:, None].expand(n_items, F))
             a = ref._starts["w_i"]
             scale[a:a + ref._sizes["w_i"]] = sb.to(torch.float32)
+            if table_merge == "one":
+                for name in ("v_if", "w_if", "v_uf"):
+                    a = ref._starts[name]
+                    scale[a:a + ref._sizes[name]] = 1.0
+            n_windows_done += 1
             if late:
                 if pending is not None:
                     apply_pending()

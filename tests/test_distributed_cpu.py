@@ -160,10 +160,15 @@ def test_fused_exchange_is_the_curvature_rule_in_one_all_reduce(tmp_path):
         assert np.array_equal(r[0]["flat%d" % x], r[1]["flat%d" % x])                             # replicas agree bit for bit
         log_rho = curvature_log_rho(0.1, SharedTables.CURVATURE_FACTORS, SharedTables.CURVATURE_BIASES, mean)
         sv, sb = curvature_scales(sum(curvature_terms(r[k]["counts"], log_rho) for k in range(world)), log_rho, world)
-        scale = np.full(T, 1.0 / world)
+        scale = np.full(T, 1.0 / world)                   # (the alignment padding between the tables)
+        for a, b in ref._table_regions():
+            scale[a:b] = 1.0
         a = ref._starts["v_i"]; scale[a:a + ref._sizes["v_i"]] = np.repeat(sv.numpy(), F)
         a = ref._starts["w_i"]; scale[a:a + ref._sizes["w_i"]] = sb.numpy()
-        cur = cur + scale * (r[0]["delta%d" % x].astype(np.float64) + r[1]["delta%d" % x])
+        total = r[0]["delta%d" % x].astype(np.float64) + r[1]["delta%d" % x]
+        for a, b in ref._table_regions():                 # the feature tables: ONE rank's delta per exchange, the ranks taking turns
+            total[a:b] = r[x % world]["delta%d" % x][a:b]
+        cur = cur + scale * total
         np.testing.assert_allclose(r[0]["flat%d" % x][:T], cur, rtol=0, atol=2e-6)
         assert r[0]["flag%d" % x] == 0.0
         mean = (vu2[0] * 10 + vu2[1] * 11) / 21.0                                                 # what the ranks agreed on for the next exchange
@@ -415,8 +420,8 @@ LATE_WINDOWS, LATE_EPOCHS = 3, 2
 
 
 def _late_counts(rank, with_counts):
-    """item update counts of a rank per epoch: zero (every item-side scale is exactly 1, the feature tables' exactly 1 / world: the
-    whole merge is dyadic arithmetic and can be compared bit for bit) or a histogram (the curvature rule's scales: compared to 1e-6)"""
+    """item update counts of a rank per epoch: zero (every item-side scale is exactly 1: the whole merge is dyadic arithmetic and can be
+    compared bit for bit) or a histogram (the curvature rule's scales: compared to 1e-6)"""
     if not with_counts:
         return np.zeros(I, np.float64)
     rng = np.random.default_rng(50 + rank)
@@ -477,7 +482,9 @@ def _late_by_hand(world, with_counts):
     def scale_of(mean):
         log_rho = curvature_log_rho(0.1, SharedTables.CURVATURE_FACTORS, SharedTables.CURVATURE_BIASES, mean)
         window = 1.0 / LATE_WINDOWS
-        scale = torch.full((T,), 1.0 / world, dtype=torch.float32)
+        scale = torch.full((T,), 1.0 / world, dtype=torch.float32)        # (the alignment padding between the tables)
+        for a, b in ref._table_regions():                                  # (the feature tables' regions: their deltas are zeroed below)
+            scale[a:b] = 1.0
         for name, lr_ in (("v_i", log_rho[0]), ("w_i", log_rho[1])):
             # (each rank's term is narrowed to float32 before the sum, like the bucket's tail)
             t = sum((-torch.expm1(lr_ * (c * window))).to(torch.float32).to(torch.float64) for c in counts)
@@ -500,6 +507,9 @@ def _late_by_hand(world, with_counts):
             for r in range(world):
                 d = _late_delta(tables[r], r, step)
                 tables[r] = tables[r] + d
+                d = d.clone()
+                for a, b in ref._table_regions():        # the feature tables stay each rank's own between exchanges (SharedTables.table_merge)
+                    d[a:b] = 0.0
                 own.append(d)
             scale = scale_of(mean_vu2)                       # rho from the mean agreed at the last COMPLETED reduction
             if pending is not None:
@@ -512,6 +522,9 @@ def _late_by_hand(world, with_counts):
         for r in range(world):
             snaps[r].append(tables[r].numpy().copy())
     apply(pending)
+    for r in range(1, world):                            # the closing broadcast of rank 0's tables
+        for a, b in ref._table_regions():
+            tables[r][a:b] = tables[0][a:b]
     return tables, snaps
 
 

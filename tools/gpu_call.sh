@@ -11,7 +11,7 @@ run_step() {
             ( timeout 600 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; tail -4 $O/smoke.log ;;
         tests)
             local log=$O/tests_$(date +%H%M%S).log
-            ( time timeout 3000 python -m pytest -x -q -m gpu "$@" ) > $log 2>&1; tail -25 $log ;;
+            ( time timeout 3000 python -m pytest -q -m gpu "$@" ) > $log 2>&1; tail -25 $log ;;
         bench)
             local tag=$1; shift
             ( timeout 1200 python bench.py "$@" ) > $O/${tag}_bench.json 2> $O/${tag}_bench.err; tail -c 2500 $O/${tag}_bench.json; tail -3 $O/${tag}_bench.err ;;
