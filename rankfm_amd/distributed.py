@@ -15,7 +15,7 @@ The reference is single-process (no counterpart to cite); the design follows SUR
     item's bias and factors settle within tens of updates, and two ranks' settled moves must not be added: measured
     +10 % on |w_i| with M = 128 in the 2-shard emulation test), never less than the plain average 1/world.  Rarely-touched rows therefore end the epoch with every rank's updates applied
     (sum of deltas), rows every rank hammered end at the ranks' average (summing K near-converged local moves
-    would overshoot K-fold), and the dense feature tables are always averaged.
+    would overshoot K-fold); the dense feature tables are ONE rank's per exchange, in turns (SharedTables.table_merge; rounds 1 - 5: their mean).
 
 Everything here works on CPU tensors with the gloo backend as well, which is how the N > 1 logic is tested
 without GPUs (tests/test_distributed_cpu.py).
