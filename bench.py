@@ -202,7 +202,8 @@ def main():
                     "(8 per epoch during a fit's first 8 epochs, 1 afterwards: rankfm_amd.distributed.ShardedTrainer)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "late", "blocking"],
                     help="N > 1: 'late' = the one-window-late merge (the all-reduce runs beside the next window's SGD, three times the cadence), "
-                         "'blocking' = every exchange blocks, 'auto' = decided after the first epoch from what an exchange and an epoch cost")
+                         "'blocking' = every exchange blocks, 'auto' = decided after the first epoch: late only where it is faster AND stable at this "
+                         "job's updates per item per window (ShardedTrainer.LATE_MOVEMENT; at the BASELINE configs' sizes that is 'blocking')")
     ap.add_argument("--factors", type=int, default=0, help="override the config's factor count (experiments)")
     ap.add_argument("--shape", type=int, default=0, help="experiment: 1-based index into the kernel shape table")
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")

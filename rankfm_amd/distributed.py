@@ -206,6 +206,21 @@ class SharedTables:
         self.merge_scale[a:a + self._sizes["w_i"]] = sb.to(torch.float32)
         self.last_curvature = dict(mean_vu2=mean_vu2, kappa_factors=lr * c_v * mean_vu2, kappa_biases=lr * c_w)
 
+    def window_movement(self, window=1.0, eta=None):
+        """how far one exchange window carries an item's bias towards where its updates pull it, by the curvature rule's own model:
+        the mean over the touched items of 1 - rho_w^(N_i window), N_i = all ranks' updates of item i per epoch.  The one-window-late
+        merge is a delay of one window in that loop, and a delayed loop with a gain near one rings (ShardedTrainer.LATE_MOVEMENT)."""
+        if getattr(self, "_curvature", None) is None or getattr(self, "_n_total", None) is None:
+            return 0.0
+        lr, c_v, c_w = self._curvature
+        if eta is not None:
+            lr = float(eta)
+        n = self._n_total[self._n_total > 0]
+        if n.numel() == 0:
+            return 0.0
+        log_rho_w = float(np.log(max(1e-12, 1.0 - min(lr * c_w, 1.0 - 1e-12))))
+        return float((1.0 - torch.exp(log_rho_w * n * float(window))).mean())
+
     def begin_epoch(self):
         self.tail.zero_()
         self.start.copy_(self.flat)
@@ -485,6 +500,16 @@ class ShardedTrainer:
     # in eight shards of a config-2-shaped problem (profiles/r05_notes.md; hit_rate@10 against the sequential oracle after 5 epochs):
     # blocking, 8 windows per epoch -0.36 point; late, 8 / 12 / 16 / 24 windows -3.2 / -1.6 / -0.87 / -0.12.  Three times the cadence.
     LATE_FACTOR = 3
+    # ... and it is a feedback loop with a delay of one window: a rank keeps pushing an item for a whole window on a state that lacks what
+    # its peers pushed in the window before.  Where one window already carries an item most of the way (SharedTables.window_movement
+    # near 1: many updates per item per window) the loop's gain is near one and the delayed loop rings.  Measured at the configurations'
+    # own sizes, eight engine shards on one GPU against one GPU on the whole data (tools/merge_c4_scan.py, profiles/r06_raw/r06k, r06l):
+    # config 5 (1 M items, 500 M rows, 24 windows / epoch, 2 epochs; movement 0.47): late |w_i| x2.20, |v_u| x3.66, |v_i| x1.57 -- blocking 0.999 /
+    # 1.004 / 1.005; eight times config 2 (the weak-scaling bench load, 3 epochs; movement 0.60): late |w_i| +7.4 %, |v_i| +4.2 % and growing --
+    # blocking +0.5 / +1.7 %.  The config-2-shaped planted problem the cadence above was measured on has a movement of 0.11 per late
+    # window and is stable.  "auto" therefore takes the late merge only when it is faster AND the movement per late window is small;
+    # overlap=True forces it (the caller's risk: check the norms against a blocking run).
+    LATE_MOVEMENT = 0.3
 
     @property
     def late(self):
@@ -512,8 +537,11 @@ class ShardedTrainer:
             dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
         T, x = float(m[0]), float(m[1])
         n = max(1, int(n_blocking))
-        self._late_on = max(T, self.LATE_FACTOR * n * x) < T + n * x
-        self.overlap_decision = dict(sgd_ms_per_epoch=T, exchange_ms=x, blocking_windows=n, late=self._late_on)
+        faster = max(T, self.LATE_FACTOR * n * x) < T + n * x
+        move = self.shared.window_movement(1.0 / (self.LATE_FACTOR * n)) if hasattr(self.shared, "window_movement") else 0.0
+        self._late_on = bool(faster and move <= self.LATE_MOVEMENT)
+        self.overlap_decision = dict(sgd_ms_per_epoch=T, exchange_ms=x, blocking_windows=n, faster=bool(faster), window_movement=move,
+                                     late=self._late_on)
 
     def _exchange(self, epoch=None, err=None, window=1.0):
         if self.fused:
@@ -815,7 +843,9 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     one window late, a final blocking exchange makes the replicas identical (SharedTables.exchange_late); it hears from the peers a
     window later and therefore runs three times the cadence (ShardedTrainer.LATE_FACTOR, measured).  False = every exchange blocks
     (rounds 2-4).  "auto" (default): the first epoch blocks and measures; the late merge is taken from the second epoch on when it
-    is the faster of the two on this job (ShardedTrainer._decide_overlap).  Only the curvature rule overlaps.
+    is the faster of the two on this job AND one of its windows moves an item only a little (ShardedTrainer._decide_overlap,
+    LATE_MOVEMENT: at configs 2 - 5's own sizes the late merge rings -- measured round 6, DESIGN.md section 8.1 -- and "auto" keeps
+    the blocking merge there; True forces it at the caller's risk).  Only the curvature rule overlaps.
 
     `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
     CPU tests; `finish()` must return the shard's trained v_u as a numpy array.

@@ -600,3 +600,18 @@ def test_auto_overlap_takes_the_late_merge_only_where_it_is_faster():
     t._decide_overlap(3.9, 0.3, 1)              # (one exchange per epoch: 0.9 ms of reductions fit behind 3.9 ms of SGD)
     assert t._late_on
     assert not t.late                           # (no curvature rule armed on one process: nothing to overlap)
+
+
+def test_auto_overlap_refuses_the_late_merge_where_a_window_moves_an_item_most_of_the_way():
+    """the one-window-late merge is a loop with a delay: with many updates per item per window its gain is near one and it rings
+    (measured at configs 5 and 8 x 2: ShardedTrainer.LATE_MOVEMENT) -- `auto` stays blocking there even when late would be faster"""
+    _, _, _, w = _problem()
+    I = w["w_i"].shape[0]
+    for per_epoch, want_late in ((90.0, True), (500.0, False), (720.0, False)):
+        shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+        shared.set_merge_curvature(np.full(I, per_epoch), 1, learning_rate=0.1, mean_vu2=1.0, n_users=10)
+        t = ShardedTrainer(shared, lambda views, epoch, part=None: dict(ll=np.zeros(1)), overlap="auto")
+        t._decide_overlap(246.0, 3.0, 8)        # (faster by the clock in all three)
+        d = t.overlap_decision
+        assert d["faster"] and d["late"] == want_late and (d["window_movement"] <= t.LATE_MOVEMENT) == want_late, d
+    assert abs(shared.window_movement(1.0 / 24) - (1.0 - 0.97 ** 30)) < 1e-9      # (720 / 24 = 30 updates at rho_w = 1 - 0.1 * 0.3)

@@ -264,6 +264,51 @@ def test_eight_engine_shards_merged_like_the_ranks_hold_the_quality_bar(c2_shape
     np.testing.assert_allclose(got[1:], want[1:], rtol=0.05)
 
 
+@pytest.mark.parametrize("late", [True, False])
+def test_eight_engine_shards_of_a_model_with_tags_hold_the_quality_bar(c2_shape_jobs, late):
+    """The same eight-shard emulation for config 4's KIND of model (8 + 8 tags, the features kernels and the table trainer in every shard; two
+    data seeds, ten epochs at learning rate 0.05 like the one-GPU tags test): the feature tables are merged as ONE rank's per exchange
+    (SharedTables.table_merge, round 6 -- their mean over eight ranks is a third of one rank's in norm, and late-corrected means diverged at
+    config 4's size: tests/test_gpu_configs.py).  hit_rate@10 within 1.5 points of the sequential oracle with tags (the one-GPU engine is
+    held to 1.0 with four engine seeds per data seed; one merged run per seed here), |v_i|, |w_i| within 5 %."""
+    import torch
+    from rankfm_amd import EngineOptions, RankFM, evaluation
+    from rankfm_amd.distributed import emulate_ranks_on_one_device
+    data, pending = c2_shape_jobs
+    loss, F, ms = C2_VARIANTS["bpr_k32_tags"]
+    hits, norms = {"oracle": [], "merged": []}, {"oracle": [], "merged": []}
+    for seed in (0, 1):
+        d = data[seed]
+        train, test = pd.DataFrame(d["train"], columns=["u", "i"]), pd.DataFrame(d["test"], columns=["u", "i"])
+        us, its = np.unique(d["train"][:, 0]), np.unique(d["train"][:, 1])
+        uf = pd.concat([pd.DataFrame({"u": us}), pd.DataFrame(d["user_tags"][us])], axis=1)
+        itf = pd.concat([pd.DataFrame({"i": its}), pd.DataFrame(d["item_tags"][its])], axis=1)
+        m = RankFM(factors=F, loss=loss, learning_rate=C2_TAG_LR, engine=EngineOptions(seed=100 + seed))
+        np.random.seed(seed)
+        m._init_all(train, uf, itf)
+        problem = dict(interactions=m.interactions, sample_weight=m.sample_weight, csr_offsets=m.user_items.offsets, csr_items=m.user_items.items,
+                       x_uf=m.x_uf, x_if=m.x_if, weights={k: getattr(m, k) for k in ("w_i", "w_if", "v_u", "v_i", "v_uf", "v_if")})
+        hyper = dict(alpha=m.alpha, beta=m.beta, learning_rate=m.learning_rate, learning_schedule=m.learning_schedule,
+                     learning_exponent=m.learning_exponent, max_samples=1)
+        out = emulate_ranks_on_one_device(problem, 8, hyper, C2_TAG_EPOCHS, torch.device("cuda", 0), syncs_per_epoch="auto", seed=100 + seed, late=late,
+                                          has_user_features=1, has_item_features=1)
+        for side, weights in (("merged", out), ("oracle", pending[("bpr_k32_tags", seed)].get(timeout=1500)["weights"])):
+            o = RankFM(factors=F, loss=loss, learning_rate=C2_TAG_LR, engine=EngineOptions(seed=100 + seed))
+            np.random.seed(seed)
+            o._init_all(train, uf, itf)
+            for k, v in weights.items():
+                setattr(o, k, np.ascontiguousarray(v))
+            o.is_fit = True
+            hits[side].append(evaluation.hit_rate(o, test, k=10))
+            norms[side].append([np.linalg.norm(getattr(o, k)) for k in ("v_u", "v_i", "w_i", "v_uf", "v_if", "w_if")])
+    mean = {k: float(np.mean(v)) for k, v in hits.items()}
+    got, want = np.mean(norms["merged"], axis=0), np.mean(norms["oracle"], axis=0)
+    print("eight engine shards WITH TAGS%s: hit_rate@10 %s means %s  norms / oracle - 1 (v_u v_i w_i v_uf v_if w_if) %s"
+          % (", late merge" if late else "", {k: np.round(v, 4).tolist() for k, v in hits.items()}, mean, np.round(got / want - 1.0, 4).tolist()))
+    assert abs(mean["merged"] - mean["oracle"]) <= 0.015, mean
+    np.testing.assert_allclose(got[1:3], want[1:3], rtol=0.05)
+
+
 def test_asynchrony_term_by_itself_at_config2_shape(c2_shape_jobs):
     """The engine's -0.6 point against the reference at config 2's shape is the sum of two unrelated effects: its
     visiting order -- user segments of <= 32 rows in a keyed order -- ranks ~1 point BETTER than the reference's row-level shuffle even

@@ -23,14 +23,24 @@ def main():
     ap.add_argument("variants")
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--config", default="C4", help="C4 or C5 (the whole data set is generated on the host: C5 = 500 M rows, ~12 GB)")
     a = ap.parse_args()
-    sh = synthetic.make_config_shard("C4", rank=0, world=1)
-    lr = sh["config"]["learning_rate"]
-    hyper = dict(alpha=0.01, beta=0.1, learning_rate=lr, learning_schedule="constant", learning_exponent=0.25, max_samples=1)
+    if a.config == "C2W":        # bench.py's weak-scaling workload at 8 GPUs as ONE data set: 8 x config 2's users and rows over its 50 k items
+        c = synthetic.CONFIGS["C2"]
+        pairs, csr = synthetic.make_interactions(c["n_users"] * a.world, c["n_items"], c["n_interactions"] * a.world, seed=0)
+        w = synthetic.init_weights(c["n_users"] * a.world, c["n_items"], c["factors"], seed=1492)
+        sh = dict(interactions=pairs, sample_weight=np.ones(len(pairs), np.float32), csr_offsets=csr.offsets, csr_items=csr.items,
+                  x_uf=np.zeros((c["n_users"] * a.world, 1), np.float32), x_if=np.zeros((c["n_items"], 1), np.float32), weights=w, config=c)
+    else:
+        sh = synthetic.make_config_shard(a.config, rank=0, world=1)
+    lr = sh["config"].get("learning_rate", 0.1)
+    ms = sh["config"]["max_samples"]
+    has_feat = bool(sh["config"].get("n_user_features", 0))
+    hyper = dict(alpha=0.01, beta=0.1, learning_rate=lr, learning_schedule="constant", learning_exponent=0.25, max_samples=ms)
     single = {}
     for variant in a.variants.split(";"):
         opts = [p for p in variant.split(",") if p]
-        feat = "nofeat" not in opts
+        feat = has_feat and "nofeat" not in opts
         x_uf = sh["x_uf"] if feat else np.zeros((len(sh["x_uf"]), 1), np.float32)
         x_if = sh["x_if"] if feat else np.zeros((len(sh["x_if"]), 1), np.float32)
         w0 = {k: np.array(v, copy=True) for k, v in sh["weights"].items()}
@@ -39,7 +49,7 @@ def main():
             w0.update(v_uf=np.zeros((1, F), np.float32), v_if=np.zeros((1, F), np.float32), w_if=np.zeros(1, np.float32))
         if feat not in single:
             one = DeviceSession(sh["interactions"], sh["sample_weight"], sh["csr_offsets"], sh["csr_items"], x_uf, x_if,
-                                {k: v.copy() for k, v in w0.items()}, max_samples=1, seed=1492, learning_rate=lr)
+                                {k: v.copy() for k, v in w0.items()}, max_samples=ms, seed=1492, learning_rate=lr)
             rep = one.run(epochs=a.epochs)
             single[feat] = (one.weights_to_host(), rep)
             del one
