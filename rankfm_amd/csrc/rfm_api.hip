@@ -391,6 +391,7 @@ static int validate(const rfm_fit_config *c) {
         t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0 || t.table_pace_pct < -1 || t.table_pace_pct > 100 || t.hot_sweep_every < 0 || t.hot_sweep_every > 64 || t.hot_slots < 0 || t.hot_slots > 128)
         return RFM_ERR_BAD_ARG;
     if (c->keep_layout != 0 && c->keep_layout != 1) return RFM_ERR_BAD_ARG;
+    if ((c->freeze_tables != 0 && c->freeze_tables != 1) || (c->freeze_tables && c->mode != RFM_MODE_HOGWILD)) return RFM_ERR_BAD_ARG;   // (the serial kernels train the tables in line)
     if (c->layout_token < 0 || (c->layout_token != 0 && c->plan_token <= 0)) return RFM_ERR_BAD_ARG;      // (a kept layout lives with its plan)
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
     if (c->rng == RFM_RNG_MT19937 && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;   // one serial stream
@@ -1120,10 +1121,14 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // most 1 / 16 of the epoch.  Measured on config 4's share: first epoch -0.5 ... +0.1 % / |w_i| -2 ... -4 % against the
         // oracle with 8 or 16 workgroups and 250 or 500 memories alike; it costs that epoch ~1 ms, every other epoch is untouched.
         int64_t head_units = 0;
+        // what keys the step producers' row sample in a launch: the launch's place in the EPOCH -- a caller's part of the epoch is a launch
+        // sequence of its own, and keyed by the window alone every part of an epoch trained the tables on the SAME sampled rows (eight parts
+        // per epoch on one GPU: -3.0 points of hit_rate@10 at config 2's shape with tags, tables +7 ... +23 %; tools/merge_tags_scan.py)
+        auto launch_key = [&](int w) -> uint32_t { return (uint32_t)w + 4099u * (uint32_t)(cfg->epoch_parts > 1 ? cfg->epoch_part_index : 0); };
         // (small launches: an eighth of their row-loop workgroups, at least one)
         const int n_rowloops = grid - 1 - n_producers;
         const int head_rowloops = std::max(1, std::min(16, n_rowloops / 8));
-        if (use_segments && feat && !single_group && !feat_frozen && n_producers > 0 && epoch == 0 && cfg->rng_epoch_offset == 0 && u_begin == 0 &&
+        if (use_segments && feat && !single_group && !feat_frozen && !cfg->freeze_tables && n_producers > 0 && epoch == 0 && cfg->rng_epoch_offset == 0 && u_begin == 0 &&
             n_rowloops >= 2 * head_rowloops && !(T.debug_flags & 64)) {
             const double memory = 1.0 / std::max(1e-6, (double)a.reg_b * (double)a.eta);
             const double frac = std::min(1.0 / 16.0, 500.0 * memory / (double)N);
@@ -1132,22 +1137,41 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         }
         if (head_units > 0) {
             const int saved_direct = a.hot_direct;
-            a.launch_index = (uint32_t)window++;
+            a.launch_index = launch_key(window++);
             a.pos_begin = u_begin;
             a.pos_end = u_begin + head_units;
             a.hot_direct = n_hot * ((cfg->n_factors + 15) / 16) + (n_hot + 15) / 16 > 4 * head_rowloops ? 1 : 0;
-            a.tickets = tickets_of((int)a.launch_index);
+            a.tickets = tickets_of(window - 1);
             a.table_quota = quota_of(a.pos_end - a.pos_begin, head_rowloops, 1.8, nullptr);
             a.table_quiet_from = 0.0f;           // (the opening launch's trainer is the slower side by design: no stop of its own)
             launch(a, 1 + n_producers + head_rowloops, stream);
             a.hot_direct = saved_direct;
         }
         for (int64_t p0 = u_begin + head_units; p0 < u_end; p0 += units_per_launch, ++window) {
-            a.launch_index = (uint32_t)window;
+            a.launch_index = launch_key(window);
+            float part_pace = 0.0f;
             a.pos_begin = p0;
             a.pos_end = p0 + units_per_launch < u_end ? p0 + units_per_launch : u_end;
             a.tickets = tickets_of(window);
             if (n_producers > 0) a.table_quota = quota_of(a.pos_end - a.pos_begin, grid - 1 - n_producers, kTableQuotaFactor, &a.table_quiet_from);
+            // A caller's PART of an epoch (multi-GPU: one exchange window): the tables keep the schedule of the EPOCH, not one of their own
+            // per launch.  An epoch in one launch spreads its quota over the first kTablePace of its segments and leaves the rest of the
+            // rows to settle on tables that have stopped moving; eight launches with that schedule each leave the model, at the end of the
+            // fit, with a quiet period an eighth as long -- too short for most users' and items' rows to be walked once -- and cost 5.0
+            // points of hit_rate@10 at config 2's shape with tags with every norm in place (one GPU, eight parts per epoch:
+            // tools/merge_tags_scan.py, profiles/r06_notes.md section 8).  So a part's launch gets the share of the EPOCH's quota that
+            // falls into its stretch of the epoch's first kTablePace, spread over that stretch; launches behind it run without a trainer.
+            bool quiet_launch = false;
+            if (n_producers > 0 && cfg->epoch_parts > 1 && T.table_pace_pct >= 0) {
+                const double P = T.table_pace_pct > 0 ? 0.01 * (double)T.table_pace_pct : (double)kTablePace;
+                const double f0 = (double)a.pos_begin / (double)units, f1 = (double)a.pos_end / (double)units;
+                const double inside = std::max(0.0, std::min(f1, P) - std::min(f0, P));
+                const int64_t epoch_quota = quota_of(units, grid - 1 - n_producers, kTableQuotaFactor, &a.table_quiet_from);
+                a.table_quota = (int64_t)((double)epoch_quota * inside / P);
+                quiet_launch = a.table_quota <= 0;
+                part_pace = (float)std::min(1.0, inside / std::max(f1 - f0, 1e-12));
+                a.table_quiet_from = 0.0f;       // (the epoch's schedule is the quiet period: no stop of the trainer's own per launch)
+            }
             // (the quota's batches spread over the first kTablePace of the launch: feat_step_producer; the opening launch above is unpaced --
             //  its trainer is the slower side by design)
             // (only beside the pipelined row loop: the generic one strides the order statically and never touches the ticket counter)
@@ -1156,6 +1180,8 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             const bool first_epoch = epoch == 0 && cfg->rng_epoch_offset == 0;
             if (n_producers > 0 && feat_fast && a.tickets && (!first_epoch || T.table_pace_pct > 0))
                 a.table_pace = T.table_pace_pct < 0 ? 0.0f : (T.table_pace_pct > 0 ? 0.01f * (float)T.table_pace_pct : kTablePace);
+            if (part_pace > 0.0f) a.table_pace = (n_producers > 0 && feat_fast && a.tickets) ? part_pace : 0.0f;
+            a.feat_frozen = (feat_frozen || quiet_launch || cfg->freeze_tables) ? 1 : 0;        // (rfm_fit_config.freeze_tables: no trainer in this call)
             launch(a, grid, stream);
         }
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));

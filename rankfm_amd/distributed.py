@@ -15,7 +15,7 @@ The reference is single-process (no counterpart to cite); the design follows SUR
     item's bias and factors settle within tens of updates, and two ranks' settled moves must not be added: measured
     +10 % on |w_i| with M = 128 in the 2-shard emulation test), never less than the plain average 1/world.  Rarely-touched rows therefore end the epoch with every rank's updates applied
     (sum of deltas), rows every rank hammered end at the ranks' average (summing K near-converged local moves
-    would overshoot K-fold); the dense feature tables are ONE rank's per exchange, in turns (SharedTables.table_merge; rounds 1 - 5: their mean).
+    would overshoot K-fold); the dense feature tables, which every row touches, are the ranks' average (SharedTables.table_merge).
 
 Everything here works on CPU tensors with the gloo backend as well, which is how the N > 1 logic is tested
 without GPUs (tests/test_distributed_cpu.py).
@@ -56,16 +56,33 @@ def take_user_shard(interactions, sample_weight, csr_offsets, csr_items, x_uf, v
 class SharedTables:
     """the replicated tables packed into one flat buffer; `views[name]` are the tensors handed to the engine"""
     kMaxWaitEvents = 4096        # (exposed_exchange_ms: event pairs kept between two readings)
-    # How the dense FEATURE tables (v_if, w_if, v_uf) are merged (round 6).  They are not sums of small steps: a rank's table trainer
-    # REPLACES them within ~170 of its steps by an exponential moving average of recent gradient noise around a slowly moving signal.
-    #   "one"   (default) a blocking exchange takes the tables of ONE rank -- the ranks take turns -- which are a sample of exactly the
-    #           process a single GPU's tables are; the late merge leaves every rank its own tables between exchanges (a late correction of a
-    #           quantity that forgets within a fraction of a window only perturbs it) and the closing broadcast hands out rank 0's;
-    #   "mean"  (rounds 1 - 5) the average over the ranks: the noise part shrinks by sqrt(ranks) -- config 4 at its own size, eight shards:
-    #           |v_if| 0.38, |w_if| 0.42 of a single GPU's -- and with the late merge at 24 windows per epoch the corrected tables destabilise
-    #           the fit (norms x 10^3 after two epochs; tests/test_gpu_configs.py, tools/merge_c4_scan.py).
-    table_merge = "one"
+    # How the dense FEATURE tables (v_if, w_if, v_uf) are merged.  They are not sums of small steps: a rank's table trainer REPLACES them
+    # within ~170 of its steps by an exponential moving average of recent gradient noise around a slowly moving signal, and most of a single
+    # trajectory's NORM is that noise.  Measured at config 2's shape with 8 + 8 tags that carry signal, ten epochs, two data seeds, eight
+    # engine shards on one GPU merged like the ranks, against ONE engine on the whole data (hit_rate@10 in points / norms of v_uf, v_if, w_if;
+    # tools/merge_tags_scan.py, profiles/r06_notes.md section 8; the one engine itself is ~1 point under the sequential oracle here):
+    #   "mean"  (default; rounds 1 - 5 and again from the end of round 6) the average of the ranks' deltas -- the saturated end of the
+    #           curvature rule: every row touches these tables.  Robust over the cadence: +1.5 points with the default cadence (8 exchanges per
+    #           epoch for 8 epochs, then 1), +2.9 at 8 throughout, +0.1 at 2, -1.7 at 1.  The noise averages out, so the merged tables are
+    #           SMALLER than a single trajectory's: -45 / -33 / -75 % at eight ranks (-21 / -17 / -18 % at two; config 4 at its own size:
+    #           |v_if| 0.38, |w_if| 0.42 of one GPU's) -- a stated deviation from a one-GPU fit's norms, on the side of the better ranking
+    #           (tables frozen at their initial values rank +2.2 points on this problem: what the tables add here is mostly noise).
+    #   "turns" the ranks take turns TRAINING them: only the rank whose turn it is runs the table trainer in a window (rfm_fit_config.
+    #           freeze_tables on the others), its delta -- the only non-zero one -- reaches everybody with the exchange.  One trajectory, norms
+    #           within 25 % of one GPU's -- but the rows of the other ranks see the tables move only at the exchanges, and that needs MANY
+    #           exchanges: -0.8 at 8 per epoch throughout, -5.9 at 2, -10.4 at 1, -6.9 with the default cadence (its last epochs exchange once).
+    #   "one"   every rank trains its own copy and a blocking exchange keeps one rank's, in turns: -0.1 at two ranks and 8 exchanges per
+    #           epoch, -4.7 at eight ranks with the default cadence -- the same dependence on the cadence, and seven ranks' work thrown away.
+    # With the late merge the tables' deltas are corrected one window late like everything else; the late merge is opt-in (ShardedTrainer.
+    # LATE_MOVEMENT) and with "turns" it diverged outright at this shape (norms x 5 ... 40).
+    table_merge = "mean"
     TABLE_NAMES = ("v_if", "w_if", "v_uf")
+
+    def my_turn(self, group=None):
+        """table_merge "turns": is this the rank that trains the feature tables in the window about to be trained?"""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return True
+        return dist.get_rank(group) == max(self._window, 0) % dist.get_world_size(group)
 
     def _table_regions(self):
         return [(self._starts[k], self._starts[k] + self._sizes[k]) for k in self.TABLE_NAMES]
@@ -94,6 +111,7 @@ class SharedTables:
         self.start = self.flat.clone()
         self._starts, self._sizes, self._shapes = starts, sizes, shapes
         self.merge_scale = None          # per-element damping of the summed deltas (None = plain sum)
+        self._window = -1                # exchange windows begun so far - 1 (begin_epoch): whose turn it is to train the feature tables
 
     def set_merge_damping(self, item_counts_all_ranks, world_size, damping=None, bias_damping=None, learning_rate=0.1):
         """per-element scale of the summed deltas: min(1, M / n_i) clipped below at 1/world_size for item i that all
@@ -163,7 +181,7 @@ class SharedTables:
         self.merge_scale = torch.full_like(self.flat, 1.0 / world_size) if world_size > 1 else None      # (feature tables with table_merge "mean": the average)
         if self.merge_scale is not None:
             self.merge_scale[self._tail_at:] = 1.0                                                       # (the tail comes back as the plain sum)
-            if self.table_merge == "one":                                                                # (ONE rank's tables come back: the sum of one delta and zeros)
+            if self.table_merge in ("one", "turns"):                                                     # (ONE rank's tables come back: the sum of one delta and zeros)
                 for a, b in self._table_regions():
                     self.merge_scale[a:b] = 1.0
         self._n_exchanges = 0
@@ -222,6 +240,7 @@ class SharedTables:
         return float((1.0 - torch.exp(log_rho_w * n * float(window))).mean())
 
     def begin_epoch(self):
+        self._window += 1
         self.tail.zero_()
         self.start.copy_(self.flat)
 
@@ -327,7 +346,8 @@ class SharedTables:
         if getattr(self, "_late_tmp", None) is None:
             self._late_tmp = torch.zeros_like(self.flat)
         torch.sub(self.flat, self.start, out=self._late_tmp)                 # this window's own delta (tail: its curvature terms)
-        if self.table_merge == "one":                                        # (the feature tables stay the rank's own until finish_late)
+        if self.table_merge == "one":                                        # (the feature tables stay the rank's own until finish_late; "turns":
+            #                                                                    the one trained copy's delta travels like everything else)
             for a, b in self._table_regions():
                 self._late_tmp[a:b].zero_()
         flag = self._late_apply()                                            # the PREVIOUS window's correction (waits for its reduction)
@@ -469,12 +489,16 @@ class ShardedTrainer:
     `DeviceSession.run` (see make_device_trainer), in the CPU tests it is any stand-in with the same contract.
     """
 
-    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None, overlap=False):
+    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None, overlap=False,
+                 tables_take_turns=False):
         self.shared, self.epoch_fn, self.group, self.average = shared, epoch_fn, group, average
         # overlap: the one-window-late merge (SharedTables.exchange_late) -- the all-reduce of a window's deltas runs beside the next
         # window's SGD; needs the fused curvature rule, and finish() before the tables are read.  True / False / "auto" (decided after
         # the first epoch from what an exchange and an epoch's SGD cost: _decide_overlap)
         self.overlap = overlap if overlap == "auto" else bool(overlap)
+        # the epoch function takes `freeze_tables` (make_device_trainer's does): with SharedTables.table_merge "turns" the ranks take turns
+        # training the feature tables, one per exchange window
+        self.tables_take_turns = bool(tables_take_turns)
         # exchanges per epoch: a number, or "auto" (the default of fit_distributed / bench.py) = AUTO_EXCHANGES per epoch during a fit's
         # first AUTO_EPOCHS epochs, one per epoch afterwards (exchanges_in_epoch).  Measured with the REAL engine in every shard
         # (tools/merge_engine_scan.py: eight shards of a config-2-shaped planted problem on one GPU, profiles/r04_notes.md): with one
@@ -611,6 +635,8 @@ class ShardedTrainer:
         waiting in the all-reduce: with the fused exchange it still joins the collective -- with zero deltas and its failure flag
         raised -- and raises afterwards (_exchange); otherwise the ranks agree on the outcome BEFORE the collective."""
         err, out = None, None
+        if self.tables_take_turns and getattr(self.shared, "table_merge", None) == "turns" and not self.shared.my_turn(self.group):
+            kw = dict(kw, freeze_tables=True)
         try:
             out = self.epoch_fn(self.shared.views, epoch, **kw)
         except Exception as e:      # noqa: BLE001 -- re-raised, on every rank
@@ -701,8 +727,8 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
     for k in SHARED_NAMES:
         assert sess.weights[k].data_ptr() == shared.views[k].data_ptr(), "shared table was copied out of the bucket"
 
-    def epoch_fn(_views, epoch, part=None):
-        return sess.run(epochs=1, epoch_begin=epoch, part=part)
+    def epoch_fn(_views, epoch, part=None, freeze_tables=False):
+        return sess.run(epochs=1, epoch_begin=epoch, part=part, freeze_tables=freeze_tables)
 
     def user_norms():           # (a device scalar: the fused exchange never reads it on the host)
         v = sess.weights["v_u"]
@@ -715,11 +741,11 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
         return lr
 
     return ShardedTrainer(shared, epoch_fn, group=group, average=average, syncs_per_epoch=syncs_per_epoch, user_norms_fn=user_norms,
-                          eta_fn=eta_of, overlap=overlap), sess
+                          eta_fn=eta_of, overlap=overlap, tables_take_turns=True), sess
 
 
 def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per_epoch=1, seed=1492, c_factors=None, c_biases=None, late=False,
-                                table_merge="one", **session_kw):
+                                table_merge="mean", **session_kw):
     """What `world` ranks would compute, on ONE GPU and in one process: `world` user shards, each trained by the REAL engine (its own
     DeviceSession, its own copy of the item-side tables, the concurrency plan a rank of that size gets), merged after every exchange
     window exactly like ShardedTrainer / SharedTables.exchange_fused merge the ranks -- curvature rule, rho from the mean |v_u|^2 of
@@ -776,7 +802,8 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
                     tr.shared.flat[:T].copy_(master)
                 before = tr.shared.flat[:T].clone()
                 if sess is not None:
-                    sess.run(epochs=1, epoch_begin=e, part=(k, n_x) if n_x > 1 else None)
+                    sess.run(epochs=1, epoch_begin=e, part=(k, n_x) if n_x > 1 else None,
+                             freeze_tables=(world > 1 and ((table_merge == "turns" and r != n_windows_done % world) or (table_merge == "turns0" and r != 0))))
                     sum_vu2 = sum_vu2 + torch.linalg.vector_norm(sess.weights["v_u"], dtype=torch.float64) ** 2
                     users += int(sess.weights["v_u"].shape[0])
                 d = tr.shared.flat[:T] - before
@@ -797,7 +824,7 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
             scale[a:a + ref._sizes["v_i"]].view(n_items, F).copy_(sv.to(torch.float32)[:, None].expand(n_items, F))
             a = ref._starts["w_i"]
             scale[a:a + ref._sizes["w_i"]] = sb.to(torch.float32)
-            if table_merge == "one":
+            if table_merge in ("one", "turns", "turns0"):
                 for name in ("v_if", "w_if", "v_uf"):
                     a = ref._starts[name]
                     scale[a:a + ref._sizes[name]] = 1.0

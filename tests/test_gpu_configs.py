@@ -229,26 +229,24 @@ def test_config5_subsample_tracks_sequential_oracle(oracle, c5_share):
     _assert_epoch_tracks_oracle(w0, g, rep, o, out, ("v_u", "v_i", "w_i"), norm_tol=0.02, ll_tol=0.02, delta_corr=0.9, draws_tol=0.05)
 
 
-@pytest.mark.parametrize("late", [False, True])
-def test_config4_eight_shards_merged_at_its_own_size_track_one_gpu(late):
+def test_config4_eight_shards_merged_at_its_own_size_track_one_gpu():
     """BASELINE config 4 is an 8-GPU configuration, and no 8-GPU node has been available: rounds 1 - 5 ran its data as ONE rank's share and
     exercised the merge across ranks at config 2's shape only.  Here the WHOLE data set -- 1 M users x 200 k items x
     50 M interactions, 32 + 32 tags, learning rate 0.03 -- is trained (a) by one engine session on one GPU and (b) as EIGHT user shards,
     each by the real engine with a rank's own concurrency plan and its own copy of the item-side tables, merged after every exchange window
     like the ranks merge (distributed.emulate_ranks_on_one_device: the curvature rule on v_i / w_i over the 52 MB bucket, the default
-    cadence of a fit's early epochs -- 8 blocking exchanges per epoch, or 24 with the one-window-late merge -- and the feature tables of ONE
-    rank per exchange, SharedTables.table_merge).  Two epochs from the same initial weights, the phase in which the model moves fastest.
+    cadence of a fit's early epochs -- 8 blocking exchanges per epoch -- and the MEAN of the ranks' feature-table deltas,
+    SharedTables.table_merge).  Two epochs from the same initial weights, the phase in which the model moves fastest.
 
-    This test found two things when it was written (tools/merge_c4_scan.py, profiles/r06_notes.md section 7): AVERAGING the feature tables
-    over the ranks, the rule of rounds 1 - 5, shrinks them to 0.38 (|v_if|) / 0.42 (|w_if|) of a single GPU's -- they are mostly gradient
-    noise with a memory of ~170 trainer steps, and the mean of eight independent noises is a third of one -- and with the LATE merge at 24
-    windows per epoch the late-corrected tables destabilised the whole fit (every norm x 10^3 after two epochs).  Since then a blocking
-    exchange hands out one rank's tables (the ranks take turns) and the late merge leaves the tables alone until its closing broadcast.
-    Measured with that rule, merged / one GPU: blocking |v_u| 1.000, |v_i| 1.022, |w_i| 1.064, tables 1.089 / 1.010 / 1.011, corr(w_i)
-    0.964; late |v_i| 1.011, |w_i| 1.120, tables 1.077 / 1.170 / 1.048, corr 0.966 (without features: |w_i| 1.055 / 1.030, corr 0.989: the
-    biases of a merged model run ahead of a single GPU's in the first epochs -- the curvature rule SUMS the ranks' deltas while steps are
-    few).  Asserted: nothing diverges; |v_u| 2 %, |v_i| 4 %, |w_i| 10 % (late: 16 %), |v_uf| 12 %, |v_if| 12 % (22 %), |w_if| 30 %, corr(w_i)
-    >= 0.95."""
+    Measured, merged / one GPU (tools/merge_c4_scan.py, profiles/r06_notes.md sections 7 - 8): |v_u| 1.000, |v_i| 1.015, |w_i| 1.045, |v_uf|
+    0.98, corr(w_i) 0.963 (the biases of a merged model run ahead of a single GPU's in the first epochs: the curvature rule SUMS the ranks'
+    deltas while steps are few) -- and |v_if| 0.375, |w_if| 0.383: the item-feature tables are mostly gradient noise with a memory of ~170
+    trainer steps, and the mean of eight ranks' independent noises is a third of one.  That shrink is a STATED deviation from a one-GPU fit:
+    the alternatives that keep the norms -- one rank's tables per exchange, or the ranks taking turns training them -- were built and
+    measured, and they rank 4.7 - 6.9 points of hit_rate@10 WORSE at config 2's shape with the default cadence where the mean ranks 1.5
+    points better than one GPU (tests/test_gpu_quality.py; here: |w_i| 1.08 / 1.29).  The one-window-late merge is not taken at this size
+    (ShardedTrainer.LATE_MOVEMENT).  Asserted: nothing diverges; |v_u| 2 %, |v_i| 4 %, |w_i| 10 %, |v_uf| 12 %, corr(w_i) >= 0.95; |v_if|
+    and |w_if| inside the band the averaging predicts (0.25 ... 0.60 of one GPU's)."""
     import torch
     from rankfm_amd import synthetic
     from rankfm_amd.distributed import emulate_ranks_on_one_device
@@ -266,15 +264,16 @@ def test_config4_eight_shards_merged_at_its_own_size_track_one_gpu(late):
     hyper = dict(alpha=0.01, beta=0.1, learning_rate=lr, learning_schedule="constant", learning_exponent=0.25, max_samples=1)
     problem = dict(interactions=sh["interactions"], sample_weight=sh["sample_weight"], csr_offsets=sh["csr_offsets"], csr_items=sh["csr_items"],
                    x_uf=sh["x_uf"], x_if=sh["x_if"], weights=w0)
-    m = emulate_ranks_on_one_device(problem, 8, hyper, E, torch.device("cuda", 0), syncs_per_epoch="auto", seed=1492, late=late,
+    m = emulate_ranks_on_one_device(problem, 8, hyper, E, torch.device("cuda", 0), syncs_per_epoch="auto", seed=1492,
                                     has_user_features=1, has_item_features=1)
     ratio = {k: float(np.linalg.norm(m[k].astype(np.float64)) / np.linalg.norm(g[k].astype(np.float64))) for k in g}
     corr = float(np.corrcoef(m["w_i"], g["w_i"])[0, 1])
-    print("config 4 whole, eight shards merged%s / one GPU after %d epochs: norms %s, corr(w_i) %.4f; one GPU: LL per update %s, SGD ms %s"
-          % (" (late merge)" if late else "", E, {k: round(v, 4) for k, v in ratio.items()}, corr, np.round(rep["log_likelihood"] / 5e7, 4),
-             np.round(rep["sgd_kernel_ms"], 1)))
+    print("config 4 whole, eight shards merged / one GPU after %d epochs: norms %s, corr(w_i) %.4f; one GPU: LL per update %s, SGD ms %s"
+          % (E, {k: round(v, 4) for k, v in ratio.items()}, corr, np.round(rep["log_likelihood"] / 5e7, 4), np.round(rep["sgd_kernel_ms"], 1)))
     assert all(np.isfinite(m[k]).all() for k in m)
-    tol = dict(v_u=0.02, v_i=0.04, w_i=0.16 if late else 0.10, v_uf=0.12, v_if=0.22 if late else 0.12, w_if=0.30)
+    tol = dict(v_u=0.02, v_i=0.04, w_i=0.10, v_uf=0.12)
     for k, t in tol.items():
         assert abs(ratio[k] - 1.0) <= t, (k, ratio[k], t, ratio)
+    for k in ("v_if", "w_if"):             # (the mean of eight ranks' noise-dominated tables: see the docstring)
+        assert 0.25 <= ratio[k] <= 0.60, (k, ratio[k], ratio)
     assert corr >= 0.95, corr
