@@ -204,6 +204,8 @@ def main():
                     help="N > 1: 'late' = the one-window-late merge (the all-reduce runs beside the next window's SGD, three times the cadence), "
                          "'blocking' = every exchange blocks, 'auto' = decided after the first epoch: late only where it is faster AND stable at this "
                          "job's updates per item per window (ShardedTrainer.LATE_MOVEMENT; at the BASELINE configs' sizes that is 'blocking')")
+    ap.add_argument("--exchange-dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="N > 1, blocking exchanges: 'bf16' = the tables' deltas travel as bfloat16 (half the payload; SharedTables.exchange_dtype)")
     ap.add_argument("--factors", type=int, default=0, help="override the config's factor count (experiments)")
     ap.add_argument("--shape", type=int, default=0, help="experiment: 1-based index into the kernel shape table")
     ap.add_argument("--share", type=int, default=8, help="configs 4 / 5 on ONE GPU: run the user shard 0 of SHARE (1 = whole data set)")
@@ -315,7 +317,8 @@ def main():
     else:
         trainer, sess = make_device_trainer(shard, {k: w[k] for k in SHARED_NAMES}, x_if, hyper, device,
                                             syncs_per_epoch=(args.syncs_per_epoch if args.syncs_per_epoch == "auto" else int(args.syncs_per_epoch)),
-                                            overlap=False if world == 1 else {"auto": "auto", "late": True, "blocking": False}[args.exchange], **session_kw)
+                                            overlap=False if world == 1 else {"auto": "auto", "late": True, "blocking": False}[args.exchange],
+                                            exchange_dtype=args.exchange_dtype, **session_kw)
         broadcast_from_rank0([trainer.shared.flat])
         trainer.shared.record_waits = world > 1          # (time the waits for late reductions: `exposed_exchange_ms_per_epoch`)
         epoch = 0
@@ -341,12 +344,23 @@ def main():
     exchange_ms = exposed_ms = None
     n_exchanges = 0
     if world > 1:
-        scratch = torch.zeros_like(trainer.shared.flat)
-        dist.all_reduce(scratch)
+        sh_ = trainer.shared
+        bf16 = args.exchange_dtype == "bf16"      # (what exchange_fused hands to RCCL: the deltas as bfloat16 + the fp32 tail beside them)
+        scratch = torch.zeros(sh_._tail_at, dtype=torch.bfloat16, device=sh_.flat.device) if bf16 else torch.zeros_like(sh_.flat)
+        scratch_tail = torch.zeros_like(sh_.tail) if bf16 else None
+
+        def one_exchange():
+            if bf16:
+                work = dist.all_reduce(scratch, async_op=True)
+                dist.all_reduce(scratch_tail)
+                work.wait()
+            else:
+                dist.all_reduce(scratch)
+        one_exchange()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        dist.all_reduce(scratch)
+        one_exchange()
         e1.record()
         torch.cuda.synchronize()
         exchange_ms = float(e0.elapsed_time(e1))
@@ -430,7 +444,7 @@ def main():
                                          % (args.warmup, args.warmup + args.steps - 1) if args.syncs_per_epoch == "auto" else "")) if world > 1 else None,
                        # (N > 1) one all-reduce of the bucket by itself, and the stream time per epoch spent WAITING for exchanges
                        "exchange": ({"payload_bytes": trainer.shared.payload_bytes, "exchange_ms": exchange_ms,
-                                     "mode": args.exchange, "late_merge_in_use": bool(trainer.late), "decision": getattr(trainer, "overlap_decision", None),
+                                     "mode": args.exchange, "dtype": args.exchange_dtype, "late_merge_in_use": bool(trainer.late), "decision": getattr(trainer, "overlap_decision", None),
                                      "exposed_exchange_ms_per_epoch": (exposed_ms / args.steps) if exposed_ms is not None else None,
                                      "waits_timed": n_exchanges} if world > 1 else None),
                        "sgd_launches_per_epoch": launches, "waves_per_launch": rep["waves_per_launch"],

@@ -77,6 +77,13 @@ class SharedTables:
     # LATE_MOVEMENT) and with "turns" it diverged outright at this shape (norms x 5 ... 40).
     table_merge = "mean"
     TABLE_NAMES = ("v_if", "w_if", "v_uf")
+    # What travels in a blocking exchange (exchange_fused).  "fp32": the bucket as it is, ONE all-reduce.  "bf16": the tables' DELTAS rounded
+    # to bfloat16 (8 bits of mantissa: a relative error of 2^-9 per element and exchange, unbiased -- round to nearest even -- on deltas that
+    # are themselves sums of noisy SGD steps; the tables stay fp32, `start + scale x sum` is fp32 arithmetic) in one all-reduce of half the
+    # bytes, the tail (curvature terms, |v_u|^2 sums, flags: they must be exact) in a second small fp32 one issued beside it.  Not the default:
+    # it changes what eight ranks compute and nothing here has met xGMI; measured in the one-GPU emulation (which rounds each shard's delta and
+    # the running sum like a ring does): profiles/r06_notes.md section 9.  The late merge always exchanges fp32.
+    exchange_dtype = "fp32"
 
     def my_turn(self, group=None):
         """table_merge "turns": is this the rank that trains the feature tables in the window about to be trained?"""
@@ -284,7 +291,16 @@ class SharedTables:
                 for a, b in self._table_regions():
                     self.flat[a:b].zero_()
         self._n_exchanges += 1
-        if world > 1:
+        if world > 1 and self.exchange_dtype == "bf16":
+            T = self._tail_at
+            if getattr(self, "_x16", None) is None:
+                self._x16 = torch.empty(T, dtype=torch.bfloat16, device=self.flat.device)
+            self._x16.copy_(self.flat[:T])
+            work = dist.all_reduce(self._x16, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            dist.all_reduce(self.tail, op=dist.ReduceOp.SUM, group=group)
+            work.wait()
+            self.flat[:T].copy_(self._x16)
+        elif world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         t_v, t_w = t[:n_items].to(torch.float64), t[n_items:2 * n_items].to(torch.float64)
         lo = 1.0 / world
@@ -449,6 +465,9 @@ class SharedTables:
 
     @property
     def payload_bytes(self):
+        """bytes a rank hands to the collective(s) of one blocking exchange"""
+        if self.exchange_dtype == "bf16":
+            return self._tail_at * 2 + self._tail_len * 4
         return self.flat.numel() * 4
 
 
@@ -707,11 +726,13 @@ def agree_on_merge_damping(shared, shard, group=None, merge_damping=None, syncs_
 
 
 def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, average=False, merge_damping=None,
-                        syncs_per_epoch=1, overlap=False, **session_kw):
+                        syncs_per_epoch=1, overlap=False, exchange_dtype="fp32", **session_kw):
     """wire a rank's shard to the HIP engine: weights are views into the flat bucket, so the engine's in-place
     atomics and the all-reduce act on the same memory"""
     from .engine import DeviceSession
     shared = SharedTables(shared_tables, device)
+    assert exchange_dtype in ("fp32", "bf16"), exchange_dtype
+    shared.exchange_dtype = exchange_dtype
     agree_on_merge_damping(shared, shard, group, merge_damping, syncs_per_epoch, hyper.get("learning_rate", 0.1))
     if len(shard["csr_offsets"]) <= 1 or len(shard["interactions"]) == 0:
         # a rank without users (more ranks than users, or a few heavy users): it trains nothing but still joins every collective
@@ -745,7 +766,7 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
 
 
 def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per_epoch=1, seed=1492, c_factors=None, c_biases=None, late=False,
-                                table_merge="mean", **session_kw):
+                                table_merge="mean", exchange_dtype="fp32", **session_kw):
     """What `world` ranks would compute, on ONE GPU and in one process: `world` user shards, each trained by the REAL engine (its own
     DeviceSession, its own copy of the item-side tables, the concurrency plan a rank of that size gets), merged after every exchange
     window exactly like ShardedTrainer / SharedTables.exchange_fused merge the ranks -- curvature rule, rho from the mean |v_u|^2 of
@@ -812,7 +833,10 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
                         a0 = ref._starts[name]
                         if late or r != n_windows_done % world:
                             d[a0:a0 + ref._sizes[name]] = 0.0
-                total += d
+                if exchange_dtype == "bf16" and not late:      # (SharedTables.exchange_dtype: each delta and the running sum rounded like a ring does)
+                    total = (total + d.to(torch.bfloat16).to(torch.float32)).to(torch.bfloat16).to(torch.float32)
+                else:
+                    total += d
                 if late:
                     own.append(d)
                 t_v += (-torch.expm1(log_rho_v * (counts[r] / n_x))).to(torch.float32).to(torch.float64)
@@ -852,7 +876,8 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
 
 
 def fit_distributed(model, interactions, user_features=None, item_features=None, sample_weight=None, epochs=1, verbose=False,
-                    group=None, device=None, merge_damping=None, syncs_per_epoch="auto", make_trainer=None, overlap="auto"):
+                    group=None, device=None, merge_damping=None, syncs_per_epoch="auto", make_trainer=None, overlap="auto",
+                    exchange_dtype="fp32"):
     """`RankFM.fit` across the ranks of a torch.distributed job (one process per GPU, `torchrun`): every rank calls it with
     the SAME arguments and the same numpy seed.
 
@@ -873,6 +898,9 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     is the faster of the two on this job AND one of its windows moves an item only a little (ShardedTrainer._decide_overlap,
     LATE_MOVEMENT: at configs 2 - 5's own sizes the late merge rings -- measured round 6, DESIGN.md section 8.1 -- and "auto" keeps
     the blocking merge there; True forces it at the caller's risk).  Only the curvature rule overlaps.
+
+    `exchange_dtype`: "fp32" (default) or "bf16" = the tables' deltas travel rounded to bfloat16, half the bytes (SharedTables.exchange_dtype;
+    blocking exchanges of the curvature rule only; free in the one-GPU emulation, never run over xGMI).
 
     `make_trainer(shard, shared_tables, x_if, hyper, device, group)` -> (ShardedTrainer, finish) replaces the HIP engine in the
     CPU tests; `finish()` must return the shard's trained v_u as a numpy array.
@@ -948,7 +976,8 @@ def fit_distributed(model, interactions, user_features=None, item_features=None,
     if make_trainer is None:
         seed = int(np.random.randint(0, 2**31 - 1)) + rank if model.engine.seed is None else int(model.engine.seed) + rank
         trainer, sess = make_device_trainer(shard, tables, model.x_if, hyper, device, group=group, merge_damping=merge_damping,
-                                            syncs_per_epoch=syncs_per_epoch, overlap=overlap if merge_damping is None else False, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
+                                            syncs_per_epoch=syncs_per_epoch, overlap=overlap if merge_damping is None else False,
+                                            exchange_dtype=exchange_dtype, seed=seed, has_user_features=int(model.x_uf.any()), has_item_features=int(model.x_if.any()),
                                             want_penalty=verbose, hogwild_damping=model.engine.damping,
                                             # every engine option of the single-GPU path applies to the shards as well
                                             debug_flags=int(model.engine.debug_flags),

@@ -648,3 +648,41 @@ def test_table_merge_turns_one_rank_trains_the_feature_tables_per_window(tmp_pat
     want = r[0]["v_if0"] + (0.5 + 1.5 + 0.5)                   # windows 0, 1, 2: ranks 0, 1, 0 trained
     np.testing.assert_allclose(r[0]["v_if"], want, atol=1e-6)
     assert np.array_equal(r[0]["v_if"], r[1]["v_if"])
+
+
+def _bf16_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, _, _, w = _problem()
+    rng = np.random.default_rng(20 + rank)
+    shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+    shared.exchange_dtype = "bf16"
+    counts = rng.integers(0, 400, I).astype(np.float64)
+    shared.set_merge_curvature(counts, world, learning_rate=0.1, mean_vu2=0.5, n_users=10)
+    shared.begin_epoch()
+    delta = torch.as_tensor(rng.normal(0, 0.01, shared._tail_at).astype(np.float32))
+    shared.flat[:shared._tail_at] += delta
+    flag = shared.exchange_fused(None, torch.tensor(5.0, dtype=torch.float64), 10, failed=rank == 1)
+    np.savez(os.path.join(out_dir, "bf16_%d.npz" % rank), flat=shared.flat.numpy().copy(), delta=delta.numpy(), start=shared.start.numpy().copy(),
+             scale=shared.merge_scale.numpy().copy(), flag=float(flag), payload=shared.payload_bytes)
+    dist.destroy_process_group()
+
+
+def test_bf16_exchange_rounds_the_deltas_only_and_keeps_the_tail_exact(tmp_path):
+    """SharedTables.exchange_dtype = "bf16" (an option): the tables' deltas travel rounded to bfloat16 and are summed in bfloat16, the tail --
+    curvature terms, |v_u|^2 sums, the failure flag -- in a second fp32 all-reduce, exact; `start + scale x sum` is fp32.  Two gloo ranks,
+    rank 1 reports a failed slice (zero deltas, flag raised): the merged tables are start + scale x bf16(rank 0's delta), bit for bit, on both."""
+    world = 2
+    mp.spawn(_bf16_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / ("bf16_%d.npz" % k)) for k in range(world)]
+    ref = SharedTables({k: _problem()[3][k] for k in SHARED_NAMES}, torch.device("cpu"))
+    T = ref._tail_at
+    assert np.array_equal(r[0]["flat"], r[1]["flat"]) and r[0]["flag"] == 1.0 and r[1]["flag"] == 1.0
+    st = torch.as_tensor(r[0]["start"][:T])
+    own = (st + torch.as_tensor(r[0]["delta"])) - st                                             # (the delta as the bucket holds it: flat - start)
+    d16 = own.to(torch.bfloat16).to(torch.float32).numpy()                                       # (rank 1's deltas are zero: its slice failed)
+    want = (torch.as_tensor(r[0]["start"][:T]) + torch.as_tensor(r[0]["scale"][:T]) * torch.as_tensor(d16)).numpy()
+    np.testing.assert_allclose(r[0]["flat"][:T], want, rtol=0, atol=1e-7)
+    assert float(np.abs(d16 - r[0]["delta"]).max()) > 0.0                                        # (the rounding is really there)
+    assert int(r[0]["payload"]) == T * 2 + ref._tail_len * 4

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 U, I, N, F = 6000, 3000, 300_000, 32
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, exchange_dtype="fp32"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -28,17 +28,19 @@ def _worker(rank, world, port, out_dir):
     pairs, _ = synthetic.make_interactions(U, I, N, seed=1)
     m = RankFM(factors=F, engine=EngineOptions(seed=9))
     np.random.seed(4)
-    fit_distributed(m, pairs, epochs=3, device=torch.device("cuda", 0))
+    fit_distributed(m, pairs, epochs=3, device=torch.device("cuda", 0), exchange_dtype=exchange_dtype)
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), v_u=m.v_u, v_i=m.v_i, w_i=m.w_i)
     dist.destroy_process_group()
 
 
-def test_fit_distributed_two_ranks_one_gpu(tmp_path, oracle):
+@pytest.mark.parametrize("exchange_dtype", ["fp32", "bf16"])
+def test_fit_distributed_two_ranks_one_gpu(tmp_path, oracle, exchange_dtype):
+    """(`bf16`: the tables' deltas travel as bfloat16, SharedTables.exchange_dtype -- the same bars)"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), exchange_dtype), nprocs=2, join=True)
     a, b = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
     for k in ("v_u", "v_i", "w_i"):
         assert np.array_equal(a[k], b[k]) and np.isfinite(a[k]).all(), k

@@ -1,6 +1,6 @@
 """GPU-box experiment: BASELINE config 4 at its own size as EIGHT user shards on one GPU (distributed.emulate_ranks_on_one_device: the real
 engine in every shard, merged like the ranks merge) against one session on the whole data -- norms and the correlation of the item biases
-after E epochs, for variants of the exchange.  A variant is a ','-separated list of  late  nofeat  syncs=<n|auto>  tables=<mean|one>.
+after E epochs, for variants of the exchange.  A variant is a ','-separated list of  late  nofeat  syncs=<n|auto>  tables=<mean|one|turns>  bf16.
 
     python tools/merge_c4_scan.py "blocking;late;late,nofeat;late,syncs=8" [--epochs 2]
 
@@ -38,6 +38,7 @@ def main():
     has_feat = bool(sh["config"].get("n_user_features", 0))
     hyper = dict(alpha=0.01, beta=0.1, learning_rate=lr, learning_schedule="constant", learning_exponent=0.25, max_samples=ms)
     single = {}
+    first = None
     for variant in a.variants.split(";"):
         opts = [p for p in variant.split(",") if p]
         feat = has_feat and "nofeat" not in opts
@@ -61,6 +62,8 @@ def main():
                 kw["syncs_per_epoch"] = o[6:] if o[6:] == "auto" else int(o[6:])
             if o.startswith("tables="):
                 kw["table_merge"] = o[7:]
+            if o == "bf16":
+                kw["exchange_dtype"] = "bf16"
         problem = dict(interactions=sh["interactions"], sample_weight=sh["sample_weight"], csr_offsets=sh["csr_offsets"], csr_items=sh["csr_items"],
                        x_uf=x_uf, x_if=x_if, weights=w0)
         m = emulate_ranks_on_one_device(problem, a.world, hyper, a.epochs, torch.device("cuda", 0), seed=1492,
@@ -68,6 +71,10 @@ def main():
         ratio = {k: round(float(np.linalg.norm(m[k].astype(np.float64)) / max(np.linalg.norm(g[k].astype(np.float64)), 1e-30)), 4) for k in g}
         print("%-32s norms merged / one GPU %s  corr(w_i) %.4f  (one GPU: LL per update %s)" % (
             variant or "blocking", ratio, float(np.corrcoef(m["w_i"], g["w_i"])[0, 1]), np.round(rep["log_likelihood"] / len(sh["interactions"]), 4)), flush=True)
+        if first is None:
+            first = m
+        else:      # (two runs of the SAME variant differ too: Hogwild is not reproducible -- list a variant twice for the noise floor)
+            print("%-32s   |x - first variant's| / |first variant's|: %s" % ("", {k: round(float(np.linalg.norm(m[k].astype(np.float64) - first[k]) / max(np.linalg.norm(first[k].astype(np.float64)), 1e-30)), 4) for k in g}), flush=True)
 
 
 if __name__ == "__main__":

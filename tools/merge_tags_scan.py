@@ -1,6 +1,6 @@
 """GPU-box experiment: a model WITH TAGS (config 4's kind: 8 + 8 binary tags, the features kernels and the table trainer in every shard) trained as
 `world` merged user shards (distributed.emulate_ranks_on_one_device) against ONE engine on the whole data: hit_rate@10 and the norms of all six
-arrays.  Variants "world:syncs:tables[:late]" separated by ';' -- tables = one | mean (SharedTables.table_merge).  No oracle (the one-GPU engine
+arrays.  Variants "world:syncs:tables[:late][:bf16]" separated by ';' -- tables = mean | one | turns (SharedTables.table_merge), bf16 = SharedTables.exchange_dtype.  No oracle (the one-GPU engine
 is held to it by tests/test_gpu_quality.py); measurement tooling, not product.
 
     python tools/merge_tags_scan.py --users 100000 --variants "8:auto:one;8:auto:mean;8:2:one;8:1:one;2:auto:one" """
@@ -55,7 +55,8 @@ def main():
         print("seed %d: %d rows, one engine done at %.0f s" % (s, len(train), time.time() - t0), flush=True)
         for v in a.variants.split(";"):
             parts = v.split(":")
-            world, syncs, tables, late = int(parts[0]), parts[1], parts[2], len(parts) > 3 and parts[3] == "late"
+            world, syncs, tables, late = int(parts[0]), parts[1], parts[2], "late" in parts[3:]
+            xd = "bf16" if "bf16" in parts[3:] else "fp32"
             m0 = RankFM(factors=a.factors, loss="bpr", learning_rate=a.learning_rate, engine=EngineOptions(seed=100 + s))
             np.random.seed(s)
             m0._init_all(train, uf, itf)
@@ -69,7 +70,7 @@ def main():
             if t:
                 kw["tune"] = t
             out = emulate_ranks_on_one_device(problem, world, hyper, a.epochs, torch.device("cuda", 0), syncs_per_epoch=(syncs if syncs == "auto" else int(syncs)),
-                                              seed=100 + s, late=late, table_merge=tables, **kw)
+                                              seed=100 + s, late=late, table_merge=tables, exchange_dtype=xd, **kw)
             for k, w in out.items():
                 setattr(m0, k, np.ascontiguousarray(w))
             m0.is_fit = True
