@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RFM_ABI_VERSION 7
+#define RFM_ABI_VERSION 6
 
 typedef enum rfm_status {
     RFM_OK = 0,
@@ -142,11 +142,6 @@ typedef struct rfm_fit_config {
                                       keep_layout = 0 on the same workspace.  rfm_fit_report.layout_token says whether it did.  A
                                       resident training loop (one call per epoch or per exchange window) saves two passes over the item
                                       tables per call. */
-    int32_t freeze_tables;         /* 1: this call reads the feature tables (v_uf, v_if, w_if) and does not train them -- its launches run
-                                      without the table trainer; everything else is updated as usual.  For multi-GPU callers whose ranks
-                                      take turns training the replicated tables (one rank per exchange window; the others' rows must not
-                                      adapt to a private copy's noise that the exchange then throws away: rankfm_amd/distributed.py).
-                                      0 = the tables are trained (rankfm/_rankfm.pyx:283-286, 313-326).  Ignored without features. */
     int64_t plan_token;            /* 0: build the Hogwild plan (user segments, CSR-ordered sample weights, per-item step
                                       scales) into the head of `workspace`; > 0: the value rfm_fit_report.plan_token returned
                                       by an earlier call on the SAME workspace, interactions, geometry and damping -- the

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librankfm_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 6
 OK = 0
 ERR_BAD_ARG, ERR_UNKNOWN_SCHEDULE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_USER_SATURATED, ERR_WORKSPACE = (
     -1, -2, -3, -4, -5, -6, -7)
@@ -41,7 +41,7 @@ class FitConfig(C.Structure):
         ("mode", C.c_int32), ("rng", C.c_int32), ("seed", C.c_uint32),
         ("check_finite", C.c_int32), ("want_penalty", C.c_int32),
         ("hogwild_damping", C.c_float),
-        ("epoch_part_index", C.c_int32), ("epoch_parts", C.c_int32), ("keep_layout", C.c_int32), ("freeze_tables", C.c_int32),
+        ("epoch_part_index", C.c_int32), ("epoch_parts", C.c_int32), ("keep_layout", C.c_int32),
         ("plan_token", C.c_int64), ("layout_token", C.c_int64),
         ("tuning", C.POINTER(FitTuning)),
     ]

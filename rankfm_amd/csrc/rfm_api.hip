@@ -391,7 +391,6 @@ static int validate(const rfm_fit_config *c) {
         t.n_workgroups < 0 || t.rows_per_launch < 0 || t.debug_shape < 0 || t.table_pace_pct < -1 || t.table_pace_pct > 100 || t.hot_sweep_every < 0 || t.hot_sweep_every > 64 || t.hot_slots < 0 || t.hot_slots > 128)
         return RFM_ERR_BAD_ARG;
     if (c->keep_layout != 0 && c->keep_layout != 1) return RFM_ERR_BAD_ARG;
-    if ((c->freeze_tables != 0 && c->freeze_tables != 1) || (c->freeze_tables && c->mode != RFM_MODE_HOGWILD)) return RFM_ERR_BAD_ARG;   // (the serial kernels train the tables in line)
     if (c->layout_token < 0 || (c->layout_token != 0 && c->plan_token <= 0)) return RFM_ERR_BAD_ARG;      // (a kept layout lives with its plan)
     if (c->rng != RFM_RNG_MT19937 && c->rng != RFM_RNG_COUNTER) return RFM_ERR_BAD_ARG;
     if (c->rng == RFM_RNG_MT19937 && c->mode != RFM_MODE_SERIAL) return RFM_ERR_BAD_ARG;   // one serial stream
@@ -1128,7 +1127,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // (small launches: an eighth of their row-loop workgroups, at least one)
         const int n_rowloops = grid - 1 - n_producers;
         const int head_rowloops = std::max(1, std::min(16, n_rowloops / 8));
-        if (use_segments && feat && !single_group && !feat_frozen && !cfg->freeze_tables && n_producers > 0 && epoch == 0 && cfg->rng_epoch_offset == 0 && u_begin == 0 &&
+        if (use_segments && feat && !single_group && !feat_frozen && n_producers > 0 && epoch == 0 && cfg->rng_epoch_offset == 0 && u_begin == 0 &&
             n_rowloops >= 2 * head_rowloops && !(T.debug_flags & 64)) {
             const double memory = 1.0 / std::max(1e-6, (double)a.reg_b * (double)a.eta);
             const double frac = std::min(1.0 / 16.0, 500.0 * memory / (double)N);
@@ -1181,7 +1180,7 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             if (n_producers > 0 && feat_fast && a.tickets && (!first_epoch || T.table_pace_pct > 0))
                 a.table_pace = T.table_pace_pct < 0 ? 0.0f : (T.table_pace_pct > 0 ? 0.01f * (float)T.table_pace_pct : kTablePace);
             if (part_pace > 0.0f) a.table_pace = (n_producers > 0 && feat_fast && a.tickets) ? part_pace : 0.0f;
-            a.feat_frozen = (feat_frozen || quiet_launch || cfg->freeze_tables) ? 1 : 0;        // (rfm_fit_config.freeze_tables: no trainer in this call)
+            a.feat_frozen = (feat_frozen || quiet_launch) ? 1 : 0;
             launch(a, grid, stream);
         }
         if (timing) RFM_HIP(hipEventRecord(ev[2 * e + 1], stream));

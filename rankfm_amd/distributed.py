@@ -67,14 +67,12 @@ class SharedTables:
     #           SMALLER than a single trajectory's: -45 / -33 / -75 % at eight ranks (-21 / -17 / -18 % at two; config 4 at its own size:
     #           |v_if| 0.38, |w_if| 0.42 of one GPU's) -- a stated deviation from a one-GPU fit's norms, on the side of the better ranking
     #           (tables frozen at their initial values rank +2.2 points on this problem: what the tables add here is mostly noise).
-    #   "turns" the ranks take turns TRAINING them: only the rank whose turn it is runs the table trainer in a window (rfm_fit_config.
-    #           freeze_tables on the others), its delta -- the only non-zero one -- reaches everybody with the exchange.  One trajectory, norms
-    #           within 25 % of one GPU's -- but the rows of the other ranks see the tables move only at the exchanges, and that needs MANY
-    #           exchanges: -0.8 at 8 per epoch throughout, -5.9 at 2, -10.4 at 1, -6.9 with the default cadence (its last epochs exchange once).
-    #   "one"   every rank trains its own copy and a blocking exchange keeps one rank's, in turns: -0.1 at two ranks and 8 exchanges per
-    #           epoch, -4.7 at eight ranks with the default cadence -- the same dependence on the cadence, and seven ranks' work thrown away.
-    # With the late merge the tables' deltas are corrected one window late like everything else; the late merge is opt-in (ShardedTrainer.
-    # LATE_MOVEMENT) and with "turns" it diverged outright at this shape (norms x 5 ... 40).
+    # Two rules that keep a single trajectory's norms were built and measured in round 6 and are NOT in the product (commit 84dc127 has them;
+    # the emulation below still takes "one"): the tables of ONE rank kept per exchange, in turns (+3 / +15 / -12 %): -4.7 points with the
+    # default cadence, -0.1 at two ranks and 8 exchanges per epoch throughout; the ranks taking turns TRAINING them while the others run
+    # without a table trainer: -6.9 (default cadence), -0.8 at 8 per epoch throughout, -5.9 at 2, -10.4 at 1, and divergence with the late
+    # merge.  The other ranks' rows see such tables move only at the exchanges, which ranks within a point only with eight or more exchanges
+    # per epoch for the whole fit; the mean keeps every rank's rows beside live tables.
     table_merge = "mean"
     TABLE_NAMES = ("v_if", "w_if", "v_uf")
     # What travels in a blocking exchange (exchange_fused).  "fp32": the bucket as it is, ONE all-reduce.  "bf16": the tables' DELTAS rounded
@@ -85,11 +83,6 @@ class SharedTables:
     # the running sum like a ring does): profiles/r06_notes.md section 9.  The late merge always exchanges fp32.
     exchange_dtype = "fp32"
 
-    def my_turn(self, group=None):
-        """table_merge "turns": is this the rank that trains the feature tables in the window about to be trained?"""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-            return True
-        return dist.get_rank(group) == max(self._window, 0) % dist.get_world_size(group)
 
     def _table_regions(self):
         return [(self._starts[k], self._starts[k] + self._sizes[k]) for k in self.TABLE_NAMES]
@@ -118,7 +111,6 @@ class SharedTables:
         self.start = self.flat.clone()
         self._starts, self._sizes, self._shapes = starts, sizes, shapes
         self.merge_scale = None          # per-element damping of the summed deltas (None = plain sum)
-        self._window = -1                # exchange windows begun so far - 1 (begin_epoch): whose turn it is to train the feature tables
 
     def set_merge_damping(self, item_counts_all_ranks, world_size, damping=None, bias_damping=None, learning_rate=0.1):
         """per-element scale of the summed deltas: min(1, M / n_i) clipped below at 1/world_size for item i that all
@@ -188,9 +180,6 @@ class SharedTables:
         self.merge_scale = torch.full_like(self.flat, 1.0 / world_size) if world_size > 1 else None      # (feature tables with table_merge "mean": the average)
         if self.merge_scale is not None:
             self.merge_scale[self._tail_at:] = 1.0                                                       # (the tail comes back as the plain sum)
-            if self.table_merge in ("one", "turns"):                                                     # (ONE rank's tables come back: the sum of one delta and zeros)
-                for a, b in self._table_regions():
-                    self.merge_scale[a:b] = 1.0
         self._n_exchanges = 0
         # exchange_fused: per-item totals over all ranks (static: summed once, here) and the mean |v_u|^2 every rank starts from
         self._n_total = self._n_local.clone()
@@ -247,7 +236,6 @@ class SharedTables:
         return float((1.0 - torch.exp(log_rho_w * n * float(window))).mean())
 
     def begin_epoch(self):
-        self._window += 1
         self.tail.zero_()
         self.start.copy_(self.flat)
 
@@ -286,10 +274,6 @@ class SharedTables:
                 _hip.raise_for_status(_hip.lib().rfm_delta_begin(self.flat.data_ptr(), self.start.data_ptr(), n, stream))
         else:
             self.flat.sub_(self.start)
-        if world > 1 and self.table_merge == "one":          # the feature tables of the rank whose turn it is
-            if (dist.get_rank(group) if group is not None else dist.get_rank()) != self._n_exchanges % world:
-                for a, b in self._table_regions():
-                    self.flat[a:b].zero_()
         self._n_exchanges += 1
         if world > 1 and self.exchange_dtype == "bf16":
             T = self._tail_at
@@ -362,10 +346,6 @@ class SharedTables:
         if getattr(self, "_late_tmp", None) is None:
             self._late_tmp = torch.zeros_like(self.flat)
         torch.sub(self.flat, self.start, out=self._late_tmp)                 # this window's own delta (tail: its curvature terms)
-        if self.table_merge == "one":                                        # (the feature tables stay the rank's own until finish_late; "turns":
-            #                                                                    the one trained copy's delta travels like everything else)
-            for a, b in self._table_regions():
-                self._late_tmp[a:b].zero_()
         flag = self._late_apply()                                            # the PREVIOUS window's correction (waits for its reduction)
         self.tail.zero_()                                                    # (the tail belongs to the exchange, not to the tables)
         # a peer failed in the previous window and has LEFT: no further collective may be launched (it would never complete), so the verdict
@@ -508,16 +488,12 @@ class ShardedTrainer:
     `DeviceSession.run` (see make_device_trainer), in the CPU tests it is any stand-in with the same contract.
     """
 
-    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None, overlap=False,
-                 tables_take_turns=False):
+    def __init__(self, shared, epoch_fn, group=None, average=False, syncs_per_epoch=1, user_norms_fn=None, eta_fn=None, overlap=False):
         self.shared, self.epoch_fn, self.group, self.average = shared, epoch_fn, group, average
         # overlap: the one-window-late merge (SharedTables.exchange_late) -- the all-reduce of a window's deltas runs beside the next
         # window's SGD; needs the fused curvature rule, and finish() before the tables are read.  True / False / "auto" (decided after
         # the first epoch from what an exchange and an epoch's SGD cost: _decide_overlap)
         self.overlap = overlap if overlap == "auto" else bool(overlap)
-        # the epoch function takes `freeze_tables` (make_device_trainer's does): with SharedTables.table_merge "turns" the ranks take turns
-        # training the feature tables, one per exchange window
-        self.tables_take_turns = bool(tables_take_turns)
         # exchanges per epoch: a number, or "auto" (the default of fit_distributed / bench.py) = AUTO_EXCHANGES per epoch during a fit's
         # first AUTO_EPOCHS epochs, one per epoch afterwards (exchanges_in_epoch).  Measured with the REAL engine in every shard
         # (tools/merge_engine_scan.py: eight shards of a config-2-shaped planted problem on one GPU, profiles/r04_notes.md): with one
@@ -654,8 +630,6 @@ class ShardedTrainer:
         waiting in the all-reduce: with the fused exchange it still joins the collective -- with zero deltas and its failure flag
         raised -- and raises afterwards (_exchange); otherwise the ranks agree on the outcome BEFORE the collective."""
         err, out = None, None
-        if self.tables_take_turns and getattr(self.shared, "table_merge", None) == "turns" and not self.shared.my_turn(self.group):
-            kw = dict(kw, freeze_tables=True)
         try:
             out = self.epoch_fn(self.shared.views, epoch, **kw)
         except Exception as e:      # noqa: BLE001 -- re-raised, on every rank
@@ -748,8 +722,8 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
     for k in SHARED_NAMES:
         assert sess.weights[k].data_ptr() == shared.views[k].data_ptr(), "shared table was copied out of the bucket"
 
-    def epoch_fn(_views, epoch, part=None, freeze_tables=False):
-        return sess.run(epochs=1, epoch_begin=epoch, part=part, freeze_tables=freeze_tables)
+    def epoch_fn(_views, epoch, part=None):
+        return sess.run(epochs=1, epoch_begin=epoch, part=part)
 
     def user_norms():           # (a device scalar: the fused exchange never reads it on the host)
         v = sess.weights["v_u"]
@@ -762,7 +736,7 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
         return lr
 
     return ShardedTrainer(shared, epoch_fn, group=group, average=average, syncs_per_epoch=syncs_per_epoch, user_norms_fn=user_norms,
-                          eta_fn=eta_of, overlap=overlap, tables_take_turns=True), sess
+                          eta_fn=eta_of, overlap=overlap), sess
 
 
 def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per_epoch=1, seed=1492, c_factors=None, c_biases=None, late=False,
@@ -823,13 +797,12 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
                     tr.shared.flat[:T].copy_(master)
                 before = tr.shared.flat[:T].clone()
                 if sess is not None:
-                    sess.run(epochs=1, epoch_begin=e, part=(k, n_x) if n_x > 1 else None,
-                             freeze_tables=(world > 1 and ((table_merge == "turns" and r != n_windows_done % world) or (table_merge == "turns0" and r != 0))))
+                    sess.run(epochs=1, epoch_begin=e, part=(k, n_x) if n_x > 1 else None)
                     sum_vu2 = sum_vu2 + torch.linalg.vector_norm(sess.weights["v_u"], dtype=torch.float64) ** 2
                     users += int(sess.weights["v_u"].shape[0])
                 d = tr.shared.flat[:T] - before
-                if table_merge == "one":          # blocking: the feature tables of ONE shard per window (the shards take turns), not the mean
-                    for name in ("v_if", "w_if", "v_uf"):     # of all; late: every shard keeps its own until the end (SharedTables.table_merge)
+                if table_merge == "one":          # (an experiment of this tool only -- the product merges the tables as the mean: the feature tables
+                    for name in ("v_if", "w_if", "v_uf"):     #  of ONE shard kept per window, in turns; late: every shard keeps its own until the end)
                         a0 = ref._starts[name]
                         if late or r != n_windows_done % world:
                             d[a0:a0 + ref._sizes[name]] = 0.0
@@ -848,7 +821,7 @@ def emulate_ranks_on_one_device(problem, world, hyper, epochs, device, syncs_per
             scale[a:a + ref._sizes["v_i"]].view(n_items, F).copy_(sv.to(torch.float32)[:, None].expand(n_items, F))
             a = ref._starts["w_i"]
             scale[a:a + ref._sizes["w_i"]] = sb.to(torch.float32)
-            if table_merge in ("one", "turns", "turns0"):
+            if table_merge == "one":
                 for name in ("v_if", "w_if", "v_uf"):
                     a = ref._starts[name]
                     scale[a:a + ref._sizes[name]] = 1.0

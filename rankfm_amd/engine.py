@@ -78,9 +78,9 @@ class DeviceSession:
         self._layout_token = 0
         self._layout_cfg = None
 
-    def _config(self, epochs, epoch_begin, part=None, rng_epoch_offset=0, freeze_tables=False):
+    def _config(self, epochs, epoch_begin, part=None, rng_epoch_offset=0):
         cfg = _hip.FitConfig(
-            rng_epoch_offset=int(rng_epoch_offset), freeze_tables=int(bool(freeze_tables)),
+            rng_epoch_offset=int(rng_epoch_offset),
             epoch_part_index=part[0] if part else 0, epoch_parts=part[1] if part else 0,
             hogwild_damping=self.hogwild_damping, plan_token=int(self._plan_token),
             keep_layout=int(self.keep_layout), layout_token=int(self._layout_token),
@@ -122,14 +122,12 @@ class DeviceSession:
         this so that the next run imports the tensors again"""
         self._layout_token = 0
 
-    def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True, part=None, rng_epoch_offset=0, freeze_tables=False):
-        """train `epochs` epochs in place on the resident tensors; returns the per-epoch report (numpy arrays).
-        `freeze_tables`: the feature tables are read, not trained, in this call (rfm_fit_config.freeze_tables: the ranks of a multi-GPU
-        job take turns training them, rankfm_amd/distributed.py)"""
-        cfg = self._config(epochs, epoch_begin, part, rng_epoch_offset, freeze_tables)    # part = (k, n): only the k-th of n slices of each epoch's order
+    def run(self, epochs=1, epoch_begin=0, perms=None, raise_on_error=True, part=None, rng_epoch_offset=0):
+        """train `epochs` epochs in place on the resident tensors; returns the per-epoch report (numpy arrays)"""
+        cfg = self._config(epochs, epoch_begin, part, rng_epoch_offset)    # part = (k, n): only the k-th of n slices of each epoch's order
         # (the workspace is sized for calls of up to RESERVE_EPOCHS epochs from the start: its per-epoch arrays are a few hundred bytes an
         #  epoch, and a longer call than the first would otherwise re-allocate it and plan again)
-        size_cfg = self._config(max(int(epochs), self.RESERVE_EPOCHS), epoch_begin, part, rng_epoch_offset, freeze_tables)
+        size_cfg = self._config(max(int(epochs), self.RESERVE_EPOCHS), epoch_begin, part, rng_epoch_offset)
         need = _hip.lib().rfm_fit_workspace_bytes(C.byref(size_cfg))
         if need == 0:
             _hip.raise_for_status(_hip.lib().rfm_fit_supported(C.byref(cfg)))

@@ -161,14 +161,9 @@ def test_fused_exchange_is_the_curvature_rule_in_one_all_reduce(tmp_path):
         log_rho = curvature_log_rho(0.1, SharedTables.CURVATURE_FACTORS, SharedTables.CURVATURE_BIASES, mean)
         sv, sb = curvature_scales(sum(curvature_terms(r[k]["counts"], log_rho) for k in range(world)), log_rho, world)
         scale = np.full(T, 1.0 / world)                   # (the alignment padding between the tables; the feature tables: the ranks' mean)
-        one = SharedTables.table_merge in ("one", "turns")
-        for a, b in ref._table_regions() if one else ():
-            scale[a:b] = 1.0
         a = ref._starts["v_i"]; scale[a:a + ref._sizes["v_i"]] = np.repeat(sv.numpy(), F)
         a = ref._starts["w_i"]; scale[a:a + ref._sizes["w_i"]] = sb.numpy()
         total = r[0]["delta%d" % x].astype(np.float64) + r[1]["delta%d" % x]
-        for a, b in ref._table_regions() if SharedTables.table_merge == "one" else ():      # ("one": ONE rank's delta per exchange, in turns)
-            total[a:b] = r[x % world]["delta%d" % x][a:b]
         cur = cur + scale * total
         np.testing.assert_allclose(r[0]["flat%d" % x][:T], cur, rtol=0, atol=2e-6)
         assert r[0]["flag%d" % x] == 0.0
@@ -484,8 +479,6 @@ def _late_by_hand(world, with_counts):
         log_rho = curvature_log_rho(0.1, SharedTables.CURVATURE_FACTORS, SharedTables.CURVATURE_BIASES, mean)
         window = 1.0 / LATE_WINDOWS
         scale = torch.full((T,), 1.0 / world, dtype=torch.float32)        # (the alignment padding between the tables)
-        for a, b in ref._table_regions() if SharedTables.table_merge in ("one", "turns") else ():      # ("mean", the default: 1 / world like the padding)
-            scale[a:b] = 1.0
         for name, lr_ in (("v_i", log_rho[0]), ("w_i", log_rho[1])):
             # (each rank's term is narrowed to float32 before the sum, like the bucket's tail)
             t = sum((-torch.expm1(lr_ * (c * window))).to(torch.float32).to(torch.float64) for c in counts)
@@ -509,8 +502,6 @@ def _late_by_hand(world, with_counts):
                 d = _late_delta(tables[r], r, step)
                 tables[r] = tables[r] + d
                 d = d.clone()
-                for a, b in ref._table_regions() if SharedTables.table_merge == "one" else ():      # ("one": they stay each rank's own between exchanges)
-                    d[a:b] = 0.0
                 own.append(d)
             scale = scale_of(mean_vu2)                       # rho from the mean agreed at the last COMPLETED reduction
             if pending is not None:
@@ -615,39 +606,6 @@ def test_auto_overlap_refuses_the_late_merge_where_a_window_moves_an_item_most_o
         d = t.overlap_decision
         assert d["faster"] and d["late"] == want_late and (d["window_movement"] <= t.LATE_MOVEMENT) == want_late, d
     assert abs(shared.window_movement(1.0 / 24) - (1.0 - 0.97 ** 30)) < 1e-9      # (720 / 24 = 30 updates at rho_w = 1 - 0.1 * 0.3)
-
-
-def _turns_worker(rank, world, port, out_dir):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    _, _, _, w = _problem()
-    shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
-    shared.table_merge = "turns"
-    shared.set_merge_curvature(np.ones(I), world, learning_rate=0.1, mean_vu2=0.5, n_users=3)
-    seen = []
-
-    def fn(views, epoch, part=None, freeze_tables=False):
-        seen.append(bool(freeze_tables))
-        views["v_i"] += 0.01 * (rank + 1)                      # (the rows always train)
-        if not freeze_tables:                                  # (the table trainer: only on the rank whose turn it is)
-            views["v_if"] += 0.5 + rank
-        return dict(ll=np.zeros(1))
-    trainer = ShardedTrainer(shared, fn, syncs_per_epoch=3, user_norms_fn=lambda: (1.0, 3), tables_take_turns=True)
-    trainer.run_epoch(0)
-    np.savez(os.path.join(out_dir, "turns%d.npz" % rank), seen=np.array(seen), v_if=shared.views["v_if"].numpy(), v_if0=np.asarray(w["v_if"]))
-    dist.destroy_process_group()
-
-
-def test_table_merge_turns_one_rank_trains_the_feature_tables_per_window(tmp_path):
-    """SharedTables.table_merge = "turns" (an option; the default is the mean): in every exchange window exactly one rank's epoch function is
-    called without freeze_tables -- rank (window % world) -- and its table delta reaches every rank unscaled"""
-    mp.spawn(_turns_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    r = [np.load(tmp_path / ("turns%d.npz" % k)) for k in range(2)]
-    assert r[0]["seen"].tolist() == [False, True, False] and r[1]["seen"].tolist() == [True, False, True]
-    want = r[0]["v_if0"] + (0.5 + 1.5 + 0.5)                   # windows 0, 1, 2: ranks 0, 1, 0 trained
-    np.testing.assert_allclose(r[0]["v_if"], want, atol=1e-6)
-    assert np.array_equal(r[0]["v_if"], r[1]["v_if"])
 
 
 def _bf16_worker(rank, world, port, out_dir):

@@ -310,41 +310,3 @@ def test_kept_engine_layout_with_a_feature_model_trains_the_same_model():
     from rankfm_amd._rankfm import _predict
     np.testing.assert_allclose(sessions[True].predict(idx), _predict(idx, x_uf, x_if, b["w_i"], b["w_if"], b["v_u"], b["v_i"], b["v_uf"], b["v_if"]),
                                rtol=1e-6, atol=1e-6)
-
-
-@pytest.mark.gpu
-def test_freeze_tables_reads_the_feature_tables_and_trains_everything_else():
-    """rfm_fit_config.freeze_tables (ABI 7; multi-GPU callers whose ranks take turns training the replicated tables): a call with it set runs
-    without the table trainer -- v_uf / v_if / w_if come back BIT-identical, the report counts no table step -- while the rows train as usual
-    (log-likelihood within 2 % of a training call from the same weights, v_u / v_i / w_i moved); a later call without it trains the tables
-    again on the same plan; the serial mode, which trains the tables in line, refuses the flag."""
-    from rankfm_amd import synthetic, _hip
-    from rankfm_amd.engine import DeviceSession
-    U, I, F, P, Q = 6000, 4000, 32, 8, 8
-    pairs, csr = synthetic.make_interactions(U, I, 400_000, seed=5)
-    sw = np.ones(len(pairs), np.float32)
-    w0 = synthetic.init_weights(U, I, F, P, Q, seed=2)
-    x_uf, x_if = synthetic.make_features(U, P, 3), synthetic.make_features(I, Q, 4)
-    s = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w0, seed=3, learning_rate=0.03)
-    ref = DeviceSession(pairs, sw, csr.offsets, csr.items, x_uf, x_if, w0, seed=3, learning_rate=0.03)
-    ll_train = ref.run(epochs=1)["log_likelihood"][0]
-    out = s.run(epochs=1, freeze_tables=True)
-    plan = s._plan_token
-    a = s.weights_to_host()
-    for k in ("v_uf", "v_if", "w_if"):
-        assert np.array_equal(a[k], np.asarray(w0[k], dtype=np.float32)), k
-    for k in ("v_u", "v_i", "w_i"):
-        assert not np.array_equal(a[k], np.asarray(w0[k], dtype=np.float32)), k
-    assert abs(out["log_likelihood"][0] / ll_train - 1.0) <= 0.02
-    for part in range(4):                                   # (parts of an epoch: frozen ones leave the tables alone as well)
-        s.run(epochs=1, epoch_begin=1, part=(part, 4), freeze_tables=True)
-    assert np.array_equal(s.weights_to_host()["v_if"], a["v_if"])
-    s.run(epochs=1, epoch_begin=2)
-    assert s._plan_token == plan                            # (the same plan: the flag is a launch decision, not a planning one)
-    b = s.weights_to_host()
-    for k in ("v_uf", "v_if", "w_if"):
-        assert not np.array_equal(a[k], b[k]), k
-    c = _csr(pairs[:2000], U)
-    serial = DeviceSession(pairs[:2000], sw[:2000], c.offsets, c.items, x_uf, x_if, w0, seed=3, learning_rate=0.03, mode="serial")
-    with pytest.raises(ValueError):
-        serial.run(epochs=1, freeze_tables=True)
