@@ -1,6 +1,6 @@
 """GPU-box experiment: BASELINE config 4 at its own size as EIGHT user shards on one GPU (distributed.emulate_ranks_on_one_device: the real
 engine in every shard, merged like the ranks merge) against one session on the whole data -- norms and the correlation of the item biases
-after E epochs, for variants of the exchange.  A variant is a ','-separated list of  late  nofeat  syncs=<n|auto>  tables=<mean|one|turns>  bf16.
+after E epochs, for variants of the exchange.  A variant is a ','-separated list of  late  nofeat  syncs=<n|auto>  tables=<mean|one>  bf16.
 
     python tools/merge_c4_scan.py "blocking;late;late,nofeat;late,syncs=8" [--epochs 2]
 

@@ -1,6 +1,6 @@
 """GPU-box experiment: a model WITH TAGS (config 4's kind: 8 + 8 binary tags, the features kernels and the table trainer in every shard) trained as
 `world` merged user shards (distributed.emulate_ranks_on_one_device) against ONE engine on the whole data: hit_rate@10 and the norms of all six
-arrays.  Variants "world:syncs:tables[:late][:bf16]" separated by ';' -- tables = mean | one | turns (SharedTables.table_merge), bf16 = SharedTables.exchange_dtype.  No oracle (the one-GPU engine
+arrays.  Variants "world:syncs:tables[:late][:bf16]" separated by ';' -- tables = mean | one (emulate_ranks_on_one_device; the product merges the mean; the 'turns' rows of profiles/r06_notes.md section 8 are commit 84dc127's), bf16 = SharedTables.exchange_dtype.  No oracle (the one-GPU engine
 is held to it by tests/test_gpu_quality.py); measurement tooling, not product.
 
     python tools/merge_tags_scan.py --users 100000 --variants "8:auto:one;8:auto:mean;8:2:one;8:1:one;2:auto:one" """
