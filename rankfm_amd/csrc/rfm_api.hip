@@ -1070,13 +1070,16 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
         // not fill a good part of the chip (fewer than 4096 row groups) keep 1.8: their row loops are latency-bound and slow per row, the
         // trainer is nowhere near their length, and the 3000 x 2000 feature fixture sits within 0.3 point of the REFERENCE there (2.4
         // ranks it a full point ABOVE the reference -- outside the bar from the other side).
-        auto quota_of = [&](int64_t n_units_launch, int rowloop_wgs, double factor, float *quiet_from) -> int64_t {
-            const double rows = (double)N * (double)n_units_launch / (double)std::max<int64_t>(1, units);
+        auto every_default_of = [&](int rowloop_wgs, double factor) -> double {
             // (in units of 64 row groups -- sixteen wavefronts -- which is what the measurement was made with)
             double rowloop_groups = (double)rowloop_wgs * (double)(waves_per_block * groups_per_wave);
             if (max_groups > 0) rowloop_groups = std::min(rowloop_groups, (double)max_groups);
             if (rowloop_groups < 4096.0) factor = std::min(factor, 1.8);
-            const double every_default = std::max(1.0, factor * rowloop_groups / 64.0);
+            return std::max(1.0, factor * rowloop_groups / 64.0);
+        };
+        auto quota_of = [&](int64_t n_units_launch, int rowloop_wgs, double factor, float *quiet_from) -> int64_t {
+            const double rows = (double)N * (double)n_units_launch / (double)std::max<int64_t>(1, units);
+            const double every_default = every_default_of(rowloop_wgs, factor);
             const double every = T.table_every > 0 ? (double)T.table_every : every_default;
             // a caller's quota DENSER than the default gets the trainer's own stop (kTableQuietFrom); the default and anything sparser
             // are done long before it and keep their exact, repeatable step count
@@ -1176,8 +1179,12 @@ static int fit_device_impl(const rfm_fit_config *cfg, const rfm_fit_buffers *b, 
             // (only beside the pipelined row loop: the generic one strides the order statically and never touches the ticket counter)
             // (and not in a fit's FIRST epoch: there the tables are leaving their initial values and every early step counts -- unpaced, the
             //  quota is front-loaded; config 4's share, first epoch against the oracle: log-likelihood +0.55 % unpaced, +1.0 % paced)
+            // (a caller's quota SPARSER than the default is paced in the first epoch as well: left to itself it is done within the launch's
+            //  first third -- config 2's shape with tags, twice the spacing, 24 runs: hit_rate@10 -1.34 point against the oracle with the
+            //  first epoch unpaced, -0.75 paced; the default -0.65 either way: profiles/r06_notes.md section 4)
             const bool first_epoch = epoch == 0 && cfg->rng_epoch_offset == 0;
-            if (n_producers > 0 && feat_fast && a.tickets && (!first_epoch || T.table_pace_pct > 0))
+            const bool sparser = T.table_every > 0 && (double)T.table_every > every_default_of(grid - 1 - n_producers, kTableQuotaFactor);
+            if (n_producers > 0 && feat_fast && a.tickets && (!first_epoch || T.table_pace_pct > 0 || sparser))
                 a.table_pace = T.table_pace_pct < 0 ? 0.0f : (T.table_pace_pct > 0 ? 0.01f * (float)T.table_pace_pct : kTablePace);
             if (part_pace > 0.0f) a.table_pace = (n_producers > 0 && feat_fast && a.tickets) ? part_pace : 0.0f;
             a.feat_frozen = (feat_frozen || quiet_launch) ? 1 : 0;
