@@ -56,8 +56,10 @@ struct RowStep {
     //  ms) and loses nothing: BPR rows of up to 64 factors keep 8 G too, for data whose users are heavier than config 2's; wider BPR rows --
     //  whose segment-major instantiations are short of registers as it is -- keep 4 G.)
     //  Factor rows of at most 32 dwords (k <= 32: BASELINE config 1's k = 20, where MovieLens-like users hold 100 - 200 items) have the
-    //  registers to spare for 16 G = 256 entries, BPR and WARP alike.
-    static constexpr int UL = (!FEAT && !SERIAL && G == 16) ? (KPL <= 2 ? 16 : ((WARPB || KPL <= 4) ? 8 : 4)) : 4;
+    //  registers to spare for 16 G = 256 entries, BPR and WARP alike.  The pipelined feature row loop (FEAT && LDSF) keeps 8 G as well since
+    //  the end of round 6: the compiler fits them into the 168 registers of its 768-thread workgroups without a spill; config 4's users hold
+    //  ~50 items and gain nothing measurable (3.58 against 3.61 ms), data with 65 - 128 items per user skip the memory path.
+    static constexpr int UL = (!FEAT && !SERIAL && G == 16) ? (KPL <= 2 ? 16 : ((WARPB || KPL <= 4) ? 8 : 4)) : ((FEAT && LDSF && !SERIAL && G == 16) ? 8 : 4);
     int32_t ulist[UL];
     bool ulist_ok = false;
     float user_scale = 1.0f;          // damping of this user's step (SgdArgs::user_cap), constant over a segment
