@@ -551,13 +551,17 @@ class ShardedTrainer:
         -- late wins when the exchanges fit behind the SGD, or still when (LATE_FACTOR - 1) n x < T.  A rank's share of config 5 (WARP,
         k = 128: T = 246 ms, x ~ 3 ms over xGMI) overlaps; config 4's (T = 3.9 ms, x ~ 0.3 ms for 52 MB) does not.  Every rank must
         decide alike: the maximum of the ranks' measurements is used."""
-        m = torch.tensor([float(sgd_ms), float(exchange_ms)], dtype=torch.float64, device=self.shared.flat.device)
+        n = max(1, int(n_blocking))
+        # (a model with trained FEATURE TABLES never takes the late merge: every row touches them, one window replaces them -- a movement of
+        #  one -- and a late correction of them destabilised config 4 at its own size, every norm x 10^3 after two epochs: DESIGN.md section 8)
+        move = self.shared.window_movement(1.0 / (self.LATE_FACTOR * n)) if hasattr(self.shared, "window_movement") else 0.0
+        if getattr(self.shared, "has_feature_tables", False):
+            move = 1.0
+        m = torch.tensor([float(sgd_ms), float(exchange_ms), float(move)], dtype=torch.float64, device=self.shared.flat.device)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
-        T, x = float(m[0]), float(m[1])
-        n = max(1, int(n_blocking))
+        T, x, move = float(m[0]), float(m[1]), float(m[2])
         faster = max(T, self.LATE_FACTOR * n * x) < T + n * x
-        move = self.shared.window_movement(1.0 / (self.LATE_FACTOR * n)) if hasattr(self.shared, "window_movement") else 0.0
         self._late_on = bool(faster and move <= self.LATE_MOVEMENT)
         self.overlap_decision = dict(sgd_ms_per_epoch=T, exchange_ms=x, blocking_windows=n, faster=bool(faster), window_movement=move,
                                      late=self._late_on)
@@ -721,6 +725,7 @@ def make_device_trainer(shard, shared_tables, x_if, hyper, device, group=None, a
     # DeviceSession.up() keeps tensors that are already resident float32 contiguous -> still the bucket views
     for k in SHARED_NAMES:
         assert sess.weights[k].data_ptr() == shared.views[k].data_ptr(), "shared table was copied out of the bucket"
+    shared.has_feature_tables = bool(sess.has_uf or sess.has_if)       # (ShardedTrainer._decide_overlap: no late merge for such a model)
 
     def epoch_fn(_views, epoch, part=None):
         return sess.run(epochs=1, epoch_begin=epoch, part=part)

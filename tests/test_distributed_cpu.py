@@ -606,6 +606,13 @@ def test_auto_overlap_refuses_the_late_merge_where_a_window_moves_an_item_most_o
         d = t.overlap_decision
         assert d["faster"] and d["late"] == want_late and (d["window_movement"] <= t.LATE_MOVEMENT) == want_late, d
     assert abs(shared.window_movement(1.0 / 24) - (1.0 - 0.97 ** 30)) < 1e-9      # (720 / 24 = 30 updates at rho_w = 1 - 0.1 * 0.3)
+    # ... and never for a model whose feature tables are trained: every row touches them (config 4 at its own size diverged with it)
+    shared = SharedTables({k: w[k] for k in SHARED_NAMES}, torch.device("cpu"))
+    shared.set_merge_curvature(np.full(I, 10.0), 1, learning_rate=0.1, mean_vu2=1.0, n_users=10)
+    shared.has_feature_tables = True
+    t = ShardedTrainer(shared, lambda views, epoch, part=None: dict(ll=np.zeros(1)), overlap="auto")
+    t._decide_overlap(246.0, 3.0, 8)
+    assert t.overlap_decision["faster"] and not t.overlap_decision["late"] and t.overlap_decision["window_movement"] == 1.0
 
 
 def _bf16_worker(rank, world, port, out_dir):
