@@ -230,8 +230,9 @@ def test_eight_engine_shards_merged_like_the_ranks_hold_the_quality_bar(c2_shape
     profiles/r04_notes.md): +0.2 point against one GPU on the whole data; with ONE exchange per epoch -13.9 after 5 epochs and +2.2
     after 15 -- which is why one exchange per epoch is not the default while the model moves fast.  (Round 3 tuned the rule against
     shards trained by the sequential oracle; this closes the loop with the asynchronous engine in every shard.)
-    `late` = the one-window-late merge, the default of fit_distributed since round 5 (the all-reduce of a window runs beside the next
-    window's SGD, SharedTables.exchange_late): the same bar; False = every exchange blocks (rounds 2-4)."""
+    `late` = the one-window-late merge (the all-reduce of a window runs beside the next window's SGD, SharedTables.exchange_late; opt-in
+    since round 6: at THIS problem's 4 positive updates per item per late window it is stable and holds the same bar, at configs 2 - 5's own
+    sizes it rings and `overlap="auto"` refuses it: ShardedTrainer.LATE_MOVEMENT); False = every exchange blocks (the default)."""
     import torch
     from rankfm_amd import EngineOptions, RankFM, evaluation
     from rankfm_amd.distributed import emulate_ranks_on_one_device
